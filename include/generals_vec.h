@@ -1,0 +1,233 @@
+/*
+ * generals_vec.h — C ABI of the MI355X-native batched Generals.io turn engine.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * mitchelldurbincs/GeneralsReinforcementLearning: the per-game turn loop of
+ * internal/game + internal/game/core (movement/combat, production, 3x3 fog of
+ * war, legal-action mask), batched over B independent boards ("envs").
+ *
+ * The reference has no FFI seam; the seam is the Go method set of *game.Engine
+ * (internal/game/engine.go:62-298).  Every entry point below names the Go
+ * symbol(s) it replaces.  A cgo shim binds these 1:1.
+ *
+ * Conventions
+ *   - All functions return int32 status: 0 = GVEC_OK, negative = API misuse /
+ *     runtime failure (never a game-rule error).  Per-env game-rule errors are
+ *     delivered in int32 err[B] using the sentinel numbering of
+ *     internal/game/core/errors.go:8-17 == proto/common/v1/common.proto:39-48.
+ *   - Buffers are caller-owned, env-major.  `mem` says where they live:
+ *     GVEC_MEM_HOST (library stages through its own pinned buffers) or
+ *     GVEC_MEM_DEVICE (pointers are HIP device pointers on the handle's device;
+ *     no host copy, work is enqueued on the handle's stream and NOT synchronised).
+ *   - Tile planes use the reference's row-major index  t = y*W + x
+ *     (core/board.go:108) with the env's OWN width W, packed at the start of a
+ *     slot of max_width*max_height elements (padded batch, SURVEY config 5).
+ *   - A handle is not thread-safe (mirrors Engine: externally serialised,
+ *     internal/grpc/gameserver/game_manager.go:576-602).
+ *   - There is NO CPU fallback behind this ABI: every compute entry point runs
+ *     hand-written HIP kernels for gfx950 and fails with GVEC_E_NO_DEVICE when no
+ *     GPU is present.
+ */
+#ifndef GENERALS_VEC_H
+#define GENERALS_VEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVEC_ABI_VERSION 1
+
+/* limits of this build */
+#define GVEC_MAX_PLAYERS 8   /* VisibleBitfield is carried as a u8 per tile            */
+#define GVEC_MAX_DIM     32  /* one board row is one u32 bit-row on the device          */
+
+/* API status (negative) */
+#define GVEC_OK            0
+#define GVEC_E_INVALID    -1  /* bad argument                                           */
+#define GVEC_E_NO_DEVICE  -2  /* no HIP device / device init failed                     */
+#define GVEC_E_HIP        -3  /* HIP runtime error (see gvec_last_error)                */
+#define GVEC_E_RANGE      -4  /* env range / size out of bounds                         */
+#define GVEC_E_BOARD      -5  /* reset/write_state input violates the board contract    */
+
+/* per-env game errors (core/errors.go:8-17; common.proto:39-48) */
+#define GVEC_ERR_NONE                 0
+#define GVEC_ERR_INVALID_COORDINATES  1
+#define GVEC_ERR_NOT_ADJACENT         2
+#define GVEC_ERR_NOT_OWNED            3
+#define GVEC_ERR_INSUFFICIENT_ARMY    4
+#define GVEC_ERR_GAME_OVER            5
+#define GVEC_ERR_INVALID_PLAYER       6
+#define GVEC_ERR_MOVE_TO_SELF         7
+#define GVEC_ERR_TARGET_IS_MOUNTAIN   8
+
+/* tile types (core/board.go:20-26) */
+#define GVEC_TILE_NORMAL   0
+#define GVEC_TILE_GENERAL  1
+#define GVEC_TILE_CITY     2
+#define GVEC_TILE_MOUNTAIN 3
+#define GVEC_NEUTRAL      (-1)
+
+#define GVEC_MEM_HOST   0
+#define GVEC_MEM_DEVICE 1
+
+/* One player's action for one turn == *core.MoveAction (core/action.go:23-36)
+ * after convertProtoAction (internal/grpc/gameserver/converters.go:105-132).
+ * Coordinates are clamped Go ints: any out-of-board value stays out of board,
+ * so MoveAction.Validate's ErrInvalidCoordinates branch is preserved.
+ * The slot index in actions[env][player] is MoveAction.PlayerID. */
+#define GVEC_ACT_VALID 1u   /* 0 = nil action (no-op this turn)                        */
+#define GVEC_ACT_HALF  2u   /* proto Action.half; MoveAll = !half                      */
+typedef struct gvec_action {
+  int8_t  from_x, from_y, to_x, to_y;
+  uint8_t flags;
+  uint8_t reserved[3];
+} gvec_action; /* 8 bytes */
+
+typedef struct gvec_config {
+  int32_t abi_version;            /* GVEC_ABI_VERSION                                    */
+  int32_t num_envs;               /* B                                                   */
+  int32_t max_width, max_height;  /* <= GVEC_MAX_DIM each                                */
+  int32_t max_players;            /* <= GVEC_MAX_PLAYERS                                 */
+  int32_t device;                 /* HIP device ordinal                                  */
+  int32_t fog_of_war;             /* GameState.FogOfWarEnabled (engine_initializer.go:118 = 1) */
+  int32_t prod_general;           /* config.go:206  game.production.general = 1          */
+  int32_t prod_city;              /* config.go:207  = 1                                  */
+  int32_t prod_normal;            /* config.go:208  = 1                                  */
+  int32_t normal_growth_interval; /* config.go:209  = 25                                 */
+  int32_t auto_reset;             /* 1: a finished env is re-dealt from the board pool on
+                                     its next step (vector-env semantics; no Go analogue) */
+  int32_t reserved[4];
+} gvec_config;
+
+typedef struct gvec_handle gvec_handle;
+
+/* Optional-plane view used by gvec_read_state / gvec_write_state.  NULL = skip.
+ * Shapes: tile planes [n][max_width*max_height]; per-player [n][max_players];
+ * scalars [n]. */
+typedef struct gvec_state_view {
+  int32_t* army;         /* Tile.Army                      (core/board.go:9)            */
+  int8_t*  owner;        /* Tile.Owner, -1 neutral         (core/board.go:8)            */
+  uint8_t* type;         /* Tile.Type                      (core/board.go:10)           */
+  uint8_t* visible;      /* Tile.VisibleBitfield, bit p    (core/board.go:11)           */
+  int8_t*  listed;       /* p iff t in Players[p].OwnedTiles, else -1 (game/state.go:12)*/
+  uint8_t* changed;      /* 1 iff t in GameState.ChangedTiles          (state.go:29)    */
+  uint8_t* vis_changed;  /* 1 iff t in GameState.VisibilityChangedTiles (state.go:33)   */
+  int32_t* turn;         /* GameState.Turn                                              */
+  uint8_t* done;         /* Engine.gameOver                 (engine.go:20)              */
+  int8_t*  winner;       /* Engine.GetWinner()              (engine.go:248-263)         */
+  int32_t* width;        /* Board.W                                                     */
+  int32_t* height;       /* Board.H                                                     */
+  int32_t* players;      /* len(GameState.Players)                                      */
+  uint8_t* alive;        /* Player.Alive                    (state.go:9)                */
+  int32_t* army_count;   /* Player.ArmyCount                (state.go:10)               */
+  int32_t* tile_count;   /* len(Player.OwnedTiles)                                      */
+  int32_t* general_idx;  /* Player.GeneralIdx (highest listed general tile, -1 if none) */
+} gvec_state_view;
+
+typedef struct gvec_rollout_stats {
+  int64_t env_steps;     /* turns actually advanced (live envs x turns)                 */
+  int64_t aborted_turns; /* turns that returned a move-validation error     */
+  int64_t games_finished;
+  int64_t captures;      /* reserved                                                    */
+} gvec_rollout_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+
+int32_t gvec_abi_version(void);
+/* Fills the reference defaults (config.go:206-209, engine_initializer.go:118). */
+int32_t gvec_config_default(gvec_config* cfg);
+/* Replaces game.NewEngine for B engines (engine.go:62-71); boards arrive via gvec_reset. */
+int32_t gvec_create(const gvec_config* cfg, gvec_handle** out);
+int32_t gvec_destroy(gvec_handle* h);
+/* Work is enqueued on this hipStream_t (default: the null stream). */
+int32_t gvec_set_stream(gvec_handle* h, void* hip_stream);
+int32_t gvec_synchronize(gvec_handle* h);
+const char* gvec_last_error(void);
+
+/* sizes */
+int32_t gvec_num_envs(const gvec_handle* h);
+int32_t gvec_tile_stride(const gvec_handle* h);   /* max_width*max_height              */
+int32_t gvec_mask_bytes(const gvec_handle* h);    /* ceil(4*tile_stride/8) per player  */
+int64_t gvec_state_bytes_per_env(const gvec_handle* h); /* resident device bytes / env */
+
+/* ---- reset: EngineInitializer.Initialize minus mapgen -------------------------
+ * (engine_initializer.go:113-143,218-225): upload boards, Turn=0, then the a15
+ * pass: full stats (stats.go:33-63), full fog (visibility_optimized.go:33-53) if
+ * fog_of_war, game-over check (engine.go:160-194).
+ * env_ids NULL => envs 0..n-1.  owner must be in [-1, P). */
+int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n,
+                   const int32_t* army, const int8_t* owner, const uint8_t* type,
+                   const int32_t* width, const int32_t* height, const int32_t* players,
+                   int32_t mem);
+
+/* Deterministic on-device map generator with the algorithm and ratios of
+ * internal/game/mapgen/generator.go:25-253 (Go math/rand is not reproducible
+ * here: boards are keyed by (seed, env) through the library's own counter RNG).
+ * Generates a board for every env (sizes per env: width/height/players arrays
+ * [B] on host, or NULL = max sizes) and runs the reset pass. */
+int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed,
+                             const int32_t* width, const int32_t* height,
+                             const int32_t* players);
+/* Pool of pre-generated boards (same sizes as env i %% pool) used by auto_reset. */
+int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed);
+
+/* ---- the hot path ---------------------------------------------------------------
+ * Engine.Step for every env (engine.go:75 -> turn_processor.go:29-77):
+ * actions[B][max_players]; err[B] receives the sentinel of the first failing move
+ * in PlayerID order (processor/action_processor.go:36-99), GVEC_ERR_GAME_OVER for
+ * a finished env (turn_processor.go:95-113), else 0.
+ * legal_bits (may be NULL): [B][max_players][mask_bytes], bit i of player p's mask
+ * = Engine.GetLegalActionMask(p)[i], i = (y*W+x)*4 + d, d = 0 up,1 right,2 down,
+ * 3 left (rules/legal_moves.go:13-18,66), computed on the post-step state. */
+int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err,
+                  uint8_t* legal_bits, int32_t mem);
+
+/* Engine.GetLegalActionMask for all envs/players (engine.go:271-280). */
+int32_t gvec_legal_mask(gvec_handle* h, uint8_t* legal_bits, int32_t mem);
+
+/* Engine.ComputePlayerVisibility(player) for all envs
+ * (visibility_optimized.go:166-195): visible/fog are [B][tile_stride] 0/1 bytes;
+ * either may be NULL. */
+int32_t gvec_player_visibility(gvec_handle* h, int32_t player,
+                               uint8_t* visible, uint8_t* fog, int32_t mem);
+
+/* Engine.GameState() / IsGameOver / GetWinner / GetChangedTiles /
+ * GetVisibilityChangedTiles (engine.go:197-198,248-298) for envs
+ * [env_begin, env_begin+n). */
+int32_t gvec_read_state(gvec_handle* h, int32_t env_begin, int32_t n,
+                        const gvec_state_view* view, int32_t mem);
+/* Raw poke of engine state (what the reference's tests do by writing e.gs.*
+ * directly, e.g. action_mask_test.go:62-68); no init pass is run. Planes that are
+ * NULL keep their current contents. */
+int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n,
+                         const gvec_state_view* view, int32_t mem);
+
+/* ---- synthetic random-agent rollouts (BASELINE.json metric) ---------------------
+ * K turns for every env with the on-device random agent of SURVEY 8(d): per alive
+ * player uniform choice over Engine.GetLegalActionMask, half with p=0.3, no-op
+ * with p=0.1, `invalid_permille`/1000 deliberately unchecked moves (H5 stress);
+ * counter RNG keyed by (seed, env, turn, player).  fused != 0 keeps board state in
+ * registers/LDS across the K turns of one launch; fused == 0 issues one step launch
+ * per turn (same results).  stats may be NULL. */
+int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed,
+                     int32_t invalid_permille, int32_t fused,
+                     gvec_rollout_stats* stats);
+/* The agent alone: fills actions[B][max_players] for the current state/turn. */
+int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille,
+                           gvec_action* actions, int32_t mem);
+
+/* ---- experience gather support ---------------------------------------
+ * Copies the compact resident records of envs [env_begin, env_begin+n) into a
+ * device buffer (e.g. a torch tensor handed to RCCL all_gather).  Record size:
+ * gvec_state_bytes_per_env(). */
+int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n,
+                            void* dst_device);
+int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n,
+                            const void* src_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENERALS_VEC_H */

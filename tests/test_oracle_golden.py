@@ -1,0 +1,192 @@
+"""Pins the CPU oracle against the known-answer vectors the reference's own Go
+tests hold (tests/golden/reference_kats.json, transcribed in make_reference_kats.py)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_kats.json")) as f:
+    CASES = json.load(f)["cases"]
+
+
+def by_kind(kind):
+    return [pytest.param(c, id=c["name"]) for c in CASES if c["kind"] == kind]
+
+
+def make_board(c):
+    L = O.lib()
+    b = L.ora_board_new(c["w"], c["h"])
+    for t in c["tiles"]:
+        tl = b.contents.t[t["y"] * c["w"] + t["x"]]
+        tl.owner, tl.army, tl.type = t.get("owner", -1), t.get("army", 0), t.get("type", 0)
+    return b
+
+
+def mk_move(a):
+    return O.Move(a["player"], a["from"][0], a["from"][1], a["to"][0], a["to"][1], int(a["move_all"]))
+
+
+def check_tiles(get_tile, w, expect_tiles):
+    for t in expect_tiles:
+        tl = get_tile(t["x"], t["y"])
+        for k in ("owner", "army", "type"):
+            if k in t:
+                assert getattr(tl, k) == t[k], (t, k, getattr(tl, k))
+
+
+def test_regenerated_json_is_current():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(HERE, "golden", "make_reference_kats.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    assert json.loads(json.dumps(mk.cases)) == CASES
+
+
+@pytest.mark.parametrize("c", by_kind("apply_move"))
+def test_apply_move(c):
+    L = O.lib()
+    b = make_board(c)
+    mv = mk_move(c["action"])
+    changed = np.zeros(c["w"] * c["h"], np.uint8)
+    cap = O.Capture()
+    captured = C.c_int32(0)
+    err = L.ora_apply_move(b, C.byref(mv), changed.ctypes.data_as(O.u8p), C.byref(cap), C.byref(captured))
+    e = c["expect"]
+    if e.get("err_nonzero"):
+        assert err != 0
+    assert err == e["err"]
+    if "capture" in e:
+        assert captured.value == 1
+        x = e["capture"]
+        assert (cap.x, cap.y, cap.tile_type, cap.capturing_player, cap.previous_owner, cap.previous_army) == \
+            (x["x"], x["y"], x["tile_type"], x["capturer"], x["prev_owner"], x["prev_army"])
+    if "captured" in e:
+        assert bool(captured.value) == e["captured"]
+    check_tiles(lambda x, y: b.contents.t[y * c["w"] + x], c["w"], e.get("tiles", []))
+    for x, y in e.get("changed", []):
+        assert changed[y * c["w"] + x] == 1
+    if "eliminations" in e:
+        out = (O.Elimination * 4)()
+        n = L.ora_process_captures(C.byref(cap), 1, out)
+        assert [[out[i].eliminated, out[i].new_owner] for i in range(n)] == e["eliminations"]
+    L.ora_board_free(b)
+
+
+@pytest.mark.parametrize("c", by_kind("validate"))
+def test_validate(c):
+    L = O.lib()
+    b = make_board(c)
+    mv = mk_move(c["action"])
+    assert L.ora_validate(b, C.byref(mv), c["player"]) == c["expect"]["err"]
+    L.ora_board_free(b)
+
+
+@pytest.mark.parametrize("c", by_kind("process_captures"))
+def test_process_captures(c):
+    L = O.lib()
+    caps = (O.Capture * max(1, len(c["captures"])))()
+    for i, x in enumerate(c["captures"]):
+        caps[i] = O.Capture(x["x"], x["y"], x["tile_type"], x["capturer"], x["prev_owner"], x["prev_army"])
+    out = (O.Elimination * 8)()
+    n = L.ora_process_captures(caps, len(c["captures"]), out)
+    assert [[out[i].eliminated, out[i].new_owner] for i in range(n)] == c["expect"]["eliminations"]
+
+
+@pytest.mark.parametrize("c", by_kind("bitfield"))
+def test_bitfield(c):
+    L = O.lib()
+    t = O.Tile()
+    for op in c["ops"]:
+        if op[0] == "set":
+            L.ora_tile_set_visible(C.byref(t), op[1], op[2])
+        elif op[0] == "raw":
+            t.visible = op[1]
+        else:
+            assert L.ora_tile_is_visible_to(C.byref(t), op[1]) == op[2], op
+
+
+def run_engine_script(c, eng):
+    """Shared interpreter for 'engine' cases; `eng` is any object with the OracleEngine surface."""
+    remembered = {}
+    for s in c["script"]:
+        op = s["op"]
+        if op == "poke":
+            eng_poke(eng, s)
+        elif op == "remember_army_count":
+            remembered[s["player"]] = eng.army_count(s["player"])
+        elif op == "step":
+            moves = [(a["player"], a["from"][0], a["from"][1], a["to"][0], a["to"][1], int(a["move_all"])) for a in s["actions"]]
+            assert eng.step(moves) == s["expect_err"]
+        elif op == "production":
+            eng.L.ora_engine_process_production(eng.e)
+        elif op == "expect":
+            if "turn" in s:
+                assert eng.turn == s["turn"]
+            if "game_over" in s:
+                assert eng.game_over == s["game_over"]
+            if "winner" in s:
+                assert eng.winner == s["winner"]
+            for p, v in s.get("alive", {}).items():
+                assert eng.alive(int(p)) == v
+            for p, v in s.get("general_idx", {}).items():
+                assert eng.general_idx(int(p)) == v
+            for p, d in s.get("army_count_delta", {}).items():
+                assert eng.army_count(int(p)) == remembered[int(p)] + d
+            check_tiles(eng.tile, eng.w, s.get("tiles", []))
+
+
+def eng_poke(eng, s):
+    L = eng.L
+    for t in s.get("tiles", []):
+        tl = eng.tile(t["x"], t["y"])
+        for k in ("owner", "army", "type"):
+            if k in t:
+                setattr(tl, k, t[k])
+    if "turn" in s:
+        L.ora_engine_set_turn(eng.e, s["turn"])
+    if "game_over" in s:
+        L.ora_engine_set_game_over(eng.e, int(s["game_over"]))
+    for p, v in s.get("alive", {}).items():
+        L.ora_player_set_alive(eng.e, int(p), int(v))
+    for p, v in s.get("general_idx", {}).items():
+        L.ora_player_set_general_idx(eng.e, int(p), v)
+
+
+@pytest.mark.parametrize("c", by_kind("engine"))
+def test_engine(c):
+    eng = O.OracleEngine(c["w"], c["h"], c["players"], c["tiles"], setup=(c["setup"] == "new_engine"))
+    run_engine_script(c, eng)
+
+
+@pytest.mark.parametrize("c", by_kind("legal_mask"))
+def test_legal_mask(c):
+    eng = O.OracleEngine(c["w"], c["h"], c["players"], c["tiles"], setup=False)
+    for p, tiles in c["owned"].items():
+        eng.set_owned(int(p), tiles)
+    for p, v in c["alive"].items():
+        eng.L.ora_player_set_alive(eng.e, int(p), int(v))
+    m = eng.legal_mask(c["query_player"])
+    check_mask_expect(m, c["expect"])
+
+
+def check_mask_expect(m, e):
+    true_idx = [int(i) for i in np.nonzero(m)[0]]
+    if "size" in e:
+        assert len(m) == e["size"]
+    if "true_indices" in e:
+        assert true_idx == e["true_indices"]
+    for i in e.get("true_indices_subset", []):
+        assert m[i]
+    for i in e.get("false_indices", []):
+        assert not m[i]
+    if "any_true_in" in e:
+        assert any(m[i] for i in e["any_true_in"])
+    if "count_gt" in e:
+        assert len(true_idx) > e["count_gt"]
+    if "count_lt" in e:
+        assert len(true_idx) < e["count_lt"]
