@@ -1,0 +1,97 @@
+"""ctypes binding of libgvec_hip.so (the C ABI of include/generals_vec.h)."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class GvecError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gvec error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32),
+                ("max_players", C.c_int32), ("device", C.c_int32), ("fog_of_war", C.c_int32), ("prod_general", C.c_int32),
+                ("prod_city", C.c_int32), ("prod_normal", C.c_int32), ("normal_growth_interval", C.c_int32),
+                ("auto_reset", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+STATE_FIELDS = ["army", "owner", "type", "visible", "listed", "changed", "vis_changed", "turn", "done", "winner", "width",
+                "height", "players", "alive", "army_count", "tile_count", "general_idx"]
+
+
+class StateView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STATE_FIELDS]
+
+
+class RolloutStats(C.Structure):
+    _fields_ = [("env_steps", C.c_int64), ("aborted_turns", C.c_int64), ("games_finished", C.c_int64), ("captures", C.c_int64)]
+
+
+# every symbol include/generals_vec.h declares: (restype, argtypes)
+_vp, _i32, _u64 = C.c_void_p, C.c_int32, C.c_uint64
+SYMBOLS = {
+    "gvec_abi_version": (_i32, []),
+    "gvec_config_default": (_i32, [C.POINTER(Config)]),
+    "gvec_create": (_i32, [C.POINTER(Config), C.POINTER(_vp)]),
+    "gvec_destroy": (_i32, [_vp]),
+    "gvec_set_stream": (_i32, [_vp, _vp]),
+    "gvec_synchronize": (_i32, [_vp]),
+    "gvec_last_error": (C.c_char_p, []),
+    "gvec_num_envs": (_i32, [_vp]),
+    "gvec_tile_stride": (_i32, [_vp]),
+    "gvec_mask_bytes": (_i32, [_vp]),
+    "gvec_state_bytes_per_env": (C.c_int64, [_vp]),
+    "gvec_reset": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "gvec_reset_generated": (_i32, [_vp, _u64, _vp, _vp, _vp]),
+    "gvec_build_board_pool": (_i32, [_vp, _i32, _u64, _vp, _vp, _vp]),
+    "gvec_step": (_i32, [_vp, _vp, _vp, _vp, _i32]),
+    "gvec_legal_mask": (_i32, [_vp, _vp, _i32]),
+    "gvec_player_visibility": (_i32, [_vp, _i32, _vp, _vp, _i32]),
+    "gvec_read_state": (_i32, [_vp, _i32, _i32, C.POINTER(StateView), _i32]),
+    "gvec_write_state": (_i32, [_vp, _i32, _i32, C.POINTER(StateView), _i32]),
+    "gvec_rollout": (_i32, [_vp, _i32, _u64, _i32, _i32, C.POINTER(RolloutStats)]),
+    "gvec_agent_actions": (_i32, [_vp, _u64, _i32, _vp, _i32]),
+    "gvec_export_records": (_i32, [_vp, _i32, _i32, _vp]),
+    "gvec_import_records": (_i32, [_vp, _i32, _i32, _vp]),
+    "gvec_device_buffer": (_vp, [_vp, _i32]),
+    "gvec_selftest": (_i32, [_i32]),
+}
+
+
+def lib_path():
+    return os.path.join(_PKG, "libgvec_hip.so")
+
+
+def load():
+    """Loads the HIP library.  Fails loudly if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GvecError(-2, f"{path} not found: build it with `python generalsreinforcementlearning_amd/csrc/build.py` "
+                            "(hipcc, gfx950). This package has no CPU fallback.")
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if L.gvec_abi_version() != 1:
+        raise GvecError(-1, "ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def lib():
+    return load()
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().gvec_last_error()
+        raise GvecError(rc, f"{what}: {msg.decode() if msg else ''}")
+    return rc

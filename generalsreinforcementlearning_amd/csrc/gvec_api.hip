@@ -1,0 +1,687 @@
+// gvec_api.hip — the C ABI of include/generals_vec.h over the HIP kernels.
+// Plain HIP runtime only (no torch, no CPU fallback): every compute entry point launches
+// gfx950 kernels and fails with GVEC_E_NO_DEVICE when there is no GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gvec_launch.hpp"
+
+using namespace gvec;
+
+static thread_local char g_err[512] = "";
+static void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return GVEC_E_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+struct gvec_handle {
+  gvec_config cfg;
+  Variant var;
+  int stride, hs, row_dw, mask_dw, mask_bytes, army_dw, maxp;
+  hipStream_t stream;
+  uint32_t* d_hdr = nullptr;
+  uint32_t* d_rows = nullptr;
+  int32_t* d_army = nullptr;
+  uint32_t* d_legal = nullptr;
+  gvec_action* d_actions = nullptr;
+  int32_t* d_err = nullptr;
+  int32_t* d_status = nullptr;
+  unsigned long long* d_counters = nullptr;  // [6]: before[3], after[3]
+  uint32_t* p_hdr = nullptr;
+  uint32_t* p_rows = nullptr;
+  int32_t* p_army = nullptr;
+  int pool_size = 0;
+  uint64_t pool_seed = 0;
+  bool legal_valid = false;
+};
+
+namespace {
+
+struct DevBuf {  // scoped device scratch
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+StepArgs base_args(const gvec_handle* h) {
+  StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army = h->d_army;
+  a.legal = h->d_legal;
+  a.pool_hdr = h->p_hdr;
+  a.pool_rows = h->p_rows;
+  a.pool_army = h->p_army;
+  a.num_envs = h->cfg.num_envs;
+  a.hs = h->hs;
+  a.row_dw = h->row_dw;
+  a.mask_dw = h->mask_dw;
+  a.pool_size = h->pool_size;
+  a.pstride = h->maxp;
+  a.prod_general = h->cfg.prod_general;
+  a.prod_city = h->cfg.prod_city;
+  a.prod_normal = h->cfg.prod_normal;
+  a.interval = h->cfg.normal_growth_interval;
+  a.turns = 1;
+  a.pool_seed_lo = (uint32_t)h->pool_seed;
+  a.pool_seed_hi = (uint32_t)(h->pool_seed >> 32);
+  if (h->cfg.auto_reset && h->pool_size > 0) a.flags |= KF_AUTORESET;
+  return a;
+}
+
+int32_t check_status(gvec_handle* h, const char* what) {
+  int32_t st = 0;
+  HIPCHK(hipMemcpyAsync(&st, h->d_status, sizeof st, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (st != 0) {
+    int32_t zero = 0;
+    HIPCHK(hipMemcpyAsync(h->d_status, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    set_err("%s: input violates the board contract (code %d: sizes within max_*, owner in [-1, players))", what, st);
+    return st;
+  }
+  return GVEC_OK;
+}
+
+// refresh the internal legal-mask buffer from the resident state
+int32_t refresh_legal(gvec_handle* h) {
+  StepArgs a = base_args(h);
+  HIPCHK(launch_legal(h->var, a, h->stream));
+  h->legal_valid = true;
+  return GVEC_OK;
+}
+
+template <typename T>
+int32_t stage_in(gvec_handle* h, DevBuf& buf, const T* src, size_t count, int32_t mem, const T** out) {
+  *out = nullptr;
+  if (!src) return GVEC_OK;
+  if (mem == GVEC_MEM_DEVICE) {
+    *out = src;
+    return GVEC_OK;
+  }
+  HIPCHK(buf.alloc(count * sizeof(T)));
+  HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  *out = buf.as<T>();
+  return GVEC_OK;
+}
+
+template <typename T>
+int32_t stage_out(DevBuf& buf, T* dst, size_t count, int32_t mem, T** out) {
+  *out = nullptr;
+  if (!dst) return GVEC_OK;
+  if (mem == GVEC_MEM_DEVICE) {
+    *out = dst;
+    return GVEC_OK;
+  }
+  HIPCHK(buf.alloc(count * sizeof(T)));
+  *out = buf.as<T>();
+  return GVEC_OK;
+}
+
+template <typename T>
+int32_t copy_out(gvec_handle* h, const DevBuf& buf, T* dst, size_t count, int32_t mem) {
+  if (!dst || mem == GVEC_MEM_DEVICE) return GVEC_OK;
+  HIPCHK(hipMemcpyAsync(dst, buf.p, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  return GVEC_OK;
+}
+
+#define RET_IF(x)                \
+  do {                           \
+    int32_t r__ = (x);           \
+    if (r__ != GVEC_OK) return r__; \
+  } while (0)
+
+int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* army, const int32_t* env_ids_dev, int dst_begin,
+                      int n, const gvec_state_view* v /*device pointers*/, bool fresh, bool init) {
+  ImportArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = hdr;
+  a.rows = rows;
+  a.army = army;
+  a.env_ids = env_ids_dev;
+  a.dst_begin = dst_begin;
+  a.n = n;
+  a.s_army = v->army;
+  a.s_owner = v->owner;
+  a.s_type = v->type;
+  a.s_visible = v->visible;
+  a.s_listed = v->listed;
+  a.s_changed = v->changed;
+  a.s_vis_changed = v->vis_changed;
+  a.s_turn = v->turn;
+  a.s_done = v->done;
+  a.s_width = v->width;
+  a.s_height = v->height;
+  a.s_players = v->players;
+  a.s_alive = v->alive;
+  a.s_army_count = v->army_count;
+  a.s_general_idx = v->general_idx;
+  a.stride = h->stride;
+  a.max_p = h->maxp;
+  a.max_w = h->cfg.max_width;
+  a.max_h = h->cfg.max_height;
+  a.hs = h->hs;
+  a.row_dw = h->row_dw;
+  a.fresh = fresh ? 1u : 0u;
+  a.init = init ? 1u : 0u;
+  a.fog = h->cfg.fog_of_war ? 1u : 0u;
+  a.status = h->d_status;
+  HIPCHK(launch_import(h->var, a, h->stream));
+  return GVEC_OK;
+}
+
+int32_t ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_err("no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return GVEC_E_NO_DEVICE;
+  }
+  return GVEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gvec_abi_version(void) { return GVEC_ABI_VERSION; }
+const char* gvec_last_error(void) { return g_err; }
+
+int32_t gvec_config_default(gvec_config* cfg) {
+  if (!cfg) return GVEC_E_INVALID;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->abi_version = GVEC_ABI_VERSION;
+  cfg->num_envs = 1;
+  cfg->max_width = 20;
+  cfg->max_height = 20;
+  cfg->max_players = 2;
+  cfg->device = 0;
+  cfg->fog_of_war = 1;              // engine_initializer.go:118
+  cfg->prod_general = 1;            // config.go:206
+  cfg->prod_city = 1;               // config.go:207
+  cfg->prod_normal = 1;             // config.go:208
+  cfg->normal_growth_interval = 25; // config.go:209
+  cfg->auto_reset = 0;
+  return GVEC_OK;
+}
+
+int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
+  if (!cfg || !out) return GVEC_E_INVALID;
+  *out = nullptr;
+  if (cfg->abi_version != GVEC_ABI_VERSION) {
+    set_err("abi_version %d != %d", cfg->abi_version, GVEC_ABI_VERSION);
+    return GVEC_E_INVALID;
+  }
+  if (cfg->num_envs < 1 || cfg->max_width < 1 || cfg->max_width > GVEC_MAX_DIM || cfg->max_height < 1 ||
+      cfg->max_height > GVEC_MAX_DIM || cfg->max_players < 1 || cfg->max_players > GVEC_MAX_PLAYERS ||
+      cfg->normal_growth_interval < 1 || cfg->prod_general < 0 || cfg->prod_city < 0 || cfg->prod_normal < 0) {
+    set_err("gvec_create: config out of range");
+    return GVEC_E_INVALID;
+  }
+  RET_IF(ensure_device());
+  HIPCHK(hipSetDevice(cfg->device));
+  gvec_handle* h = new (std::nothrow) gvec_handle();
+  if (!h) return GVEC_E_INVALID;
+  h->cfg = *cfg;
+  h->stride = cfg->max_width * cfg->max_height;
+  h->maxp = cfg->max_players;
+  if (!pick_variant(cfg->max_players, h->stride, &h->var)) {
+    delete h;
+    set_err("no kernel variant for %d players / %d tiles", cfg->max_players, h->stride);
+    return GVEC_E_INVALID;
+  }
+  h->hs = (int)round_up((size_t)cfg->max_height, 4);
+  h->row_dw = (3 * h->var.maxp + 5) * h->hs;
+  h->army_dw = h->var.nslot * 64;
+  h->mask_bytes = (int)round_up((size_t)(h->stride + 1) / 2, 16);
+  h->mask_dw = h->mask_bytes / 4;
+  h->stream = nullptr;
+  const size_t B = (size_t)cfg->num_envs;
+  HIPCHK(hipMalloc(&h->d_hdr, B * HDR_DW * 4));
+  HIPCHK(hipMalloc(&h->d_rows, B * h->row_dw * 4));
+  HIPCHK(hipMalloc(&h->d_army, B * h->army_dw * 4));
+  HIPCHK(hipMalloc(&h->d_legal, B * h->maxp * h->mask_bytes));
+  HIPCHK(hipMalloc(&h->d_actions, B * h->maxp * sizeof(gvec_action)));
+  HIPCHK(hipMalloc(&h->d_err, B * 4));
+  HIPCHK(hipMalloc(&h->d_status, 16));
+  HIPCHK(hipMalloc(&h->d_counters, 6 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(h->d_rows, 0, B * h->row_dw * 4));
+  HIPCHK(hipMemset(h->d_army, 0, B * h->army_dw * 4));
+  HIPCHK(hipMemset(h->d_legal, 0, B * h->maxp * h->mask_bytes));
+  HIPCHK(hipMemset(h->d_actions, 0, B * h->maxp * sizeof(gvec_action)));
+  HIPCHK(hipMemset(h->d_err, 0, B * 4));
+  HIPCHK(hipMemset(h->d_status, 0, 16));
+  {  // every slot starts as a finished 1x1 one-player game, so any kernel is safe before gvec_reset
+    std::vector<uint32_t> hdr(B * HDR_DW, 0u);
+    for (size_t e = 0; e < B; ++e) {
+      uint32_t* x = &hdr[e * HDR_DW];
+      x[H_DIMS] = 1u | (1u << 8) | (1u << 16) | ((HF_DONE | (cfg->fog_of_war ? HF_FOG : 0u)) << 24);
+      x[H_RECIPW] = 65536u;
+      for (int p = 0; p < 8; ++p) x[H_GIDX + p] = 0xFFFFFFFFu;
+    }
+    HIPCHK(hipMemcpy(h->d_hdr, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+  }
+  h->legal_valid = true;
+  *out = h;
+  return GVEC_OK;
+}
+
+int32_t gvec_destroy(gvec_handle* h) {
+  if (!h) return GVEC_E_INVALID;
+  (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters, h->p_hdr, h->p_rows, h->p_army};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+  return GVEC_OK;
+}
+
+int32_t gvec_set_stream(gvec_handle* h, void* hip_stream) {
+  if (!h) return GVEC_E_INVALID;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return GVEC_OK;
+}
+int32_t gvec_synchronize(gvec_handle* h) {
+  if (!h) return GVEC_E_INVALID;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_num_envs(const gvec_handle* h) { return h ? h->cfg.num_envs : GVEC_E_INVALID; }
+int32_t gvec_tile_stride(const gvec_handle* h) { return h ? h->stride : GVEC_E_INVALID; }
+int32_t gvec_mask_bytes(const gvec_handle* h) { return h ? h->mask_bytes : GVEC_E_INVALID; }
+int64_t gvec_state_bytes_per_env(const gvec_handle* h) {
+  return h ? (int64_t)4 * (HDR_DW + h->row_dw + h->army_dw) : (int64_t)GVEC_E_INVALID;
+}
+
+int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int32_t* army, const int8_t* owner,
+                   const uint8_t* type, const int32_t* width, const int32_t* height, const int32_t* players, int32_t mem) {
+  if (!h || n < 0 || !army || !owner || !type || !width || !height || !players) return GVEC_E_INVALID;
+  if (n == 0) return GVEC_OK;
+  if (!env_ids && n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (env_ids && mem == GVEC_MEM_HOST)
+    for (int i = 0; i < n; ++i)
+      if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return GVEC_E_RANGE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  DevBuf b_ids, b_army, b_owner, b_type, b_w, b_h, b_p;
+  const size_t nt = (size_t)n * h->stride;
+  gvec_state_view v;
+  memset(&v, 0, sizeof v);
+  const int32_t* ids = nullptr;
+  RET_IF(stage_in(h, b_ids, env_ids, (size_t)n, mem, &ids));
+  RET_IF(stage_in(h, b_army, army, nt, mem, (const int32_t**)&v.army));
+  RET_IF(stage_in(h, b_owner, owner, nt, mem, (const int8_t**)&v.owner));
+  RET_IF(stage_in(h, b_type, type, nt, mem, (const uint8_t**)&v.type));
+  RET_IF(stage_in(h, b_w, width, (size_t)n, mem, (const int32_t**)&v.width));
+  RET_IF(stage_in(h, b_h, height, (size_t)n, mem, (const int32_t**)&v.height));
+  RET_IF(stage_in(h, b_p, players, (size_t)n, mem, (const int32_t**)&v.players));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, ids, 0, n, &v, true, true));
+  RET_IF(check_status(h, "gvec_reset"));
+  return refresh_legal(h);
+}
+
+static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* army, int count, uint64_t seed,
+                             const int32_t* width, const int32_t* height, const int32_t* players) {
+  const int chunk = 65536;
+  DevBuf b_army, b_owner, b_type, b_w, b_h, b_p, b_iw, b_ih, b_ip;
+  const int cn = count < chunk ? count : chunk;
+  HIPCHK(b_army.alloc((size_t)cn * h->stride * 4));
+  HIPCHK(b_owner.alloc((size_t)cn * h->stride));
+  HIPCHK(b_type.alloc((size_t)cn * h->stride));
+  HIPCHK(b_w.alloc((size_t)cn * 4));
+  HIPCHK(b_h.alloc((size_t)cn * 4));
+  HIPCHK(b_p.alloc((size_t)cn * 4));
+  if (width) HIPCHK(b_iw.alloc((size_t)cn * 4));
+  if (height) HIPCHK(b_ih.alloc((size_t)cn * 4));
+  if (players) HIPCHK(b_ip.alloc((size_t)cn * 4));
+  for (int first = 0; first < count; first += chunk) {
+    const int n = (count - first) < chunk ? (count - first) : chunk;
+    if (width) HIPCHK(hipMemcpyAsync(b_iw.p, width + first, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (height) HIPCHK(hipMemcpyAsync(b_ih.p, height + first, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (players) HIPCHK(hipMemcpyAsync(b_ip.p, players + first, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    MapgenArgs m;
+    memset(&m, 0, sizeof m);
+    m.army = b_army.as<int32_t>();
+    m.owner = b_owner.as<int8_t>();
+    m.type = b_type.as<uint8_t>();
+    m.width = b_w.as<int32_t>();
+    m.height = b_h.as<int32_t>();
+    m.players = b_p.as<int32_t>();
+    m.in_width = width ? b_iw.as<int32_t>() : nullptr;
+    m.in_height = height ? b_ih.as<int32_t>() : nullptr;
+    m.in_players = players ? b_ip.as<int32_t>() : nullptr;
+    m.n = n;
+    m.stride = h->stride;
+    m.max_w = h->cfg.max_width;
+    m.max_h = h->cfg.max_height;
+    m.max_p = h->maxp;
+    m.first_index = first;
+    m.seed_lo = (uint32_t)seed;
+    m.seed_hi = (uint32_t)(seed >> 32);
+    m.status = h->d_status;
+    HIPCHK(launch_mapgen(m, h->stream));
+    gvec_state_view v;
+    memset(&v, 0, sizeof v);
+    v.army = m.army;
+    v.owner = m.owner;
+    v.type = m.type;
+    v.width = m.width;
+    v.height = m.height;
+    v.players = m.players;
+    RET_IF(import_planes(h, hdr, rows, army, nullptr, first, n, &v, true, true));
+    HIPCHK(hipStreamSynchronize(h->stream));  // staging is reused by the next chunk
+  }
+  return check_status(h, "map generation");
+}
+
+int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed, const int32_t* width, const int32_t* height,
+                             const int32_t* players) {
+  if (!h) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army, h->cfg.num_envs, seed, width, height, players));
+  return refresh_legal(h);
+}
+
+int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed, const int32_t* width, const int32_t* height,
+                              const int32_t* players) {
+  if (!h || pool_size < 1) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->p_hdr) (void)hipFree(h->p_hdr);
+  if (h->p_rows) (void)hipFree(h->p_rows);
+  if (h->p_army) (void)hipFree(h->p_army);
+  h->p_hdr = nullptr;
+  h->p_rows = nullptr;
+  h->p_army = nullptr;
+  h->pool_size = 0;
+  HIPCHK(hipMalloc(&h->p_hdr, (size_t)pool_size * HDR_DW * 4));
+  HIPCHK(hipMalloc(&h->p_rows, (size_t)pool_size * h->row_dw * 4));
+  HIPCHK(hipMalloc(&h->p_army, (size_t)pool_size * h->army_dw * 4));
+  RET_IF(generate_into(h, h->p_hdr, h->p_rows, h->p_army, pool_size, seed, width, height, players));
+  h->pool_size = pool_size;
+  h->pool_seed = seed;
+  return GVEC_OK;
+}
+
+int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err, uint8_t* legal_bits, int32_t mem) {
+  if (!h || !actions) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->cfg.num_envs;
+  StepArgs a = base_args(h);
+  if (mem == GVEC_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(h->d_actions, actions, B * h->maxp * sizeof(gvec_action), hipMemcpyHostToDevice, h->stream));
+    a.actions = h->d_actions;
+    a.err = err ? h->d_err : nullptr;
+  } else {
+    a.actions = actions;
+    a.err = err;
+  }
+  if (legal_bits) a.flags |= KF_EMIT;
+  HIPCHK(launch_step(h->var, a, h->stream));
+  h->legal_valid = legal_bits != nullptr;
+  if (mem == GVEC_MEM_HOST) {
+    if (err) HIPCHK(hipMemcpyAsync(err, h->d_err, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (legal_bits) HIPCHK(hipMemcpyAsync(legal_bits, h->d_legal, B * h->maxp * h->mask_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else if (legal_bits && legal_bits != reinterpret_cast<uint8_t*>(h->d_legal)) {
+    HIPCHK(hipMemcpyAsync(legal_bits, h->d_legal, B * h->maxp * h->mask_bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return GVEC_OK;
+}
+
+int32_t gvec_legal_mask(gvec_handle* h, uint8_t* legal_bits, int32_t mem) {
+  if (!h || !legal_bits) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->legal_valid) RET_IF(refresh_legal(h));
+  const size_t bytes = (size_t)h->cfg.num_envs * h->maxp * h->mask_bytes;
+  if (mem == GVEC_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(legal_bits, h->d_legal, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else if (legal_bits != reinterpret_cast<uint8_t*>(h->d_legal)) {
+    HIPCHK(hipMemcpyAsync(legal_bits, h->d_legal, bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return GVEC_OK;
+}
+
+static int32_t export_range(gvec_handle* h, int32_t env_begin, int32_t n, const gvec_state_view* view, int32_t vis_player,
+                            uint8_t* pv_visible, uint8_t* pv_fog, int32_t mem) {
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0) return GVEC_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nt = (size_t)n * h->stride, np = (size_t)n * h->maxp, ne = (size_t)n;
+  static const gvec_state_view kEmpty = {};
+  const gvec_state_view* v = view ? view : &kEmpty;
+  DevBuf b[19];
+  ExportArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army = h->d_army;
+  a.env_begin = env_begin;
+  a.n = n;
+  a.stride = h->stride;
+  a.max_p = h->maxp;
+  a.hs = h->hs;
+  a.row_dw = h->row_dw;
+  a.vis_player = vis_player;
+  RET_IF(stage_out(b[0], v->army, nt, mem, &a.army_out));
+  RET_IF(stage_out(b[1], v->owner, nt, mem, &a.owner));
+  RET_IF(stage_out(b[2], v->type, nt, mem, &a.type));
+  RET_IF(stage_out(b[3], v->visible, nt, mem, &a.visible));
+  RET_IF(stage_out(b[4], v->listed, nt, mem, &a.listed));
+  RET_IF(stage_out(b[5], v->changed, nt, mem, &a.changed));
+  RET_IF(stage_out(b[6], v->vis_changed, nt, mem, &a.vis_changed));
+  RET_IF(stage_out(b[7], v->turn, ne, mem, &a.turn));
+  RET_IF(stage_out(b[8], v->done, ne, mem, &a.done));
+  RET_IF(stage_out(b[9], v->winner, ne, mem, &a.winner));
+  RET_IF(stage_out(b[10], v->width, ne, mem, &a.width));
+  RET_IF(stage_out(b[11], v->height, ne, mem, &a.height));
+  RET_IF(stage_out(b[12], v->players, ne, mem, &a.players));
+  RET_IF(stage_out(b[13], v->alive, np, mem, &a.alive));
+  RET_IF(stage_out(b[14], v->army_count, np, mem, &a.army_count));
+  RET_IF(stage_out(b[15], v->tile_count, np, mem, &a.tile_count));
+  RET_IF(stage_out(b[16], v->general_idx, np, mem, &a.general_idx));
+  RET_IF(stage_out(b[17], pv_visible, nt, mem, &a.pv_visible));
+  RET_IF(stage_out(b[18], pv_fog, nt, mem, &a.pv_fog));
+  HIPCHK(launch_export(h->var, a, h->stream));
+  RET_IF(copy_out(h, b[0], v->army, nt, mem));
+  RET_IF(copy_out(h, b[1], v->owner, nt, mem));
+  RET_IF(copy_out(h, b[2], v->type, nt, mem));
+  RET_IF(copy_out(h, b[3], v->visible, nt, mem));
+  RET_IF(copy_out(h, b[4], v->listed, nt, mem));
+  RET_IF(copy_out(h, b[5], v->changed, nt, mem));
+  RET_IF(copy_out(h, b[6], v->vis_changed, nt, mem));
+  RET_IF(copy_out(h, b[7], v->turn, ne, mem));
+  RET_IF(copy_out(h, b[8], v->done, ne, mem));
+  RET_IF(copy_out(h, b[9], v->winner, ne, mem));
+  RET_IF(copy_out(h, b[10], v->width, ne, mem));
+  RET_IF(copy_out(h, b[11], v->height, ne, mem));
+  RET_IF(copy_out(h, b[12], v->players, ne, mem));
+  RET_IF(copy_out(h, b[13], v->alive, np, mem));
+  RET_IF(copy_out(h, b[14], v->army_count, np, mem));
+  RET_IF(copy_out(h, b[15], v->tile_count, np, mem));
+  RET_IF(copy_out(h, b[16], v->general_idx, np, mem));
+  RET_IF(copy_out(h, b[17], pv_visible, nt, mem));
+  RET_IF(copy_out(h, b[18], pv_fog, nt, mem));
+  if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_player_visibility(gvec_handle* h, int32_t player, uint8_t* visible, uint8_t* fog, int32_t mem) {
+  if (!h) return GVEC_E_INVALID;
+  return export_range(h, 0, h->cfg.num_envs, nullptr, player, visible, fog, mem);
+}
+
+int32_t gvec_read_state(gvec_handle* h, int32_t env_begin, int32_t n, const gvec_state_view* view, int32_t mem) {
+  if (!h || !view) return GVEC_E_INVALID;
+  return export_range(h, env_begin, n, view, -1, nullptr, nullptr, mem);
+}
+
+int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gvec_state_view* view, int32_t mem) {
+  if (!h || !view) return GVEC_E_INVALID;
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0) return GVEC_OK;
+  if (view->width || view->height || view->players) {
+    set_err("gvec_write_state cannot change board dimensions or player count; use gvec_reset");
+    return GVEC_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nt = (size_t)n * h->stride, np = (size_t)n * h->maxp, ne = (size_t)n;
+  DevBuf b[12];
+  gvec_state_view v;
+  memset(&v, 0, sizeof v);
+  RET_IF(stage_in(h, b[0], view->army, nt, mem, (const int32_t**)&v.army));
+  RET_IF(stage_in(h, b[1], view->owner, nt, mem, (const int8_t**)&v.owner));
+  RET_IF(stage_in(h, b[2], view->type, nt, mem, (const uint8_t**)&v.type));
+  RET_IF(stage_in(h, b[3], view->visible, nt, mem, (const uint8_t**)&v.visible));
+  RET_IF(stage_in(h, b[4], view->listed, nt, mem, (const int8_t**)&v.listed));
+  RET_IF(stage_in(h, b[5], view->changed, nt, mem, (const uint8_t**)&v.changed));
+  RET_IF(stage_in(h, b[6], view->vis_changed, nt, mem, (const uint8_t**)&v.vis_changed));
+  RET_IF(stage_in(h, b[7], view->turn, ne, mem, (const int32_t**)&v.turn));
+  RET_IF(stage_in(h, b[8], view->done, ne, mem, (const uint8_t**)&v.done));
+  RET_IF(stage_in(h, b[9], view->alive, np, mem, (const uint8_t**)&v.alive));
+  RET_IF(stage_in(h, b[10], view->army_count, np, mem, (const int32_t**)&v.army_count));
+  RET_IF(stage_in(h, b[11], view->general_idx, np, mem, (const int32_t**)&v.general_idx));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, nullptr, env_begin, n, &v, false, false));
+  RET_IF(check_status(h, "gvec_write_state"));
+  return refresh_legal(h);
+}
+
+int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t fused,
+                     gvec_rollout_stats* stats) {
+  if (!h || turns < 0) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (stats) {
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, 6 * sizeof(unsigned long long), h->stream));
+    HIPCHK(launch_counter_sum(h->d_hdr, h->cfg.num_envs, h->d_counters, h->stream));
+  }
+  StepArgs a = base_args(h);
+  a.flags |= KF_AGENT | KF_EMIT;
+  a.seed_lo = (uint32_t)seed;
+  a.seed_hi = (uint32_t)(seed >> 32);
+  a.invalid_permille = invalid_permille;
+  if (fused) {
+    a.turns = turns;
+    if (h->legal_valid) a.flags |= KF_LMVALID;
+    if (turns > 0) HIPCHK(launch_step(h->var, a, h->stream));
+  } else {
+    a.turns = 1;
+    for (int k = 0; k < turns; ++k) {
+      if (h->legal_valid) a.flags |= KF_LMVALID;
+      HIPCHK(launch_step(h->var, a, h->stream));
+      h->legal_valid = true;
+    }
+  }
+  if (turns > 0) h->legal_valid = true;
+  if (stats) {
+    HIPCHK(launch_counter_sum(h->d_hdr, h->cfg.num_envs, h->d_counters + 3, h->stream));
+    unsigned long long c[6];
+    HIPCHK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    stats->env_steps = (int64_t)(c[3] - c[0]);
+    stats->aborted_turns = (int64_t)(c[4] - c[1]);
+    stats->games_finished = (int64_t)(c[5] - c[2]);
+    stats->captures = 0;
+  }
+  return GVEC_OK;
+}
+
+int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille, gvec_action* actions, int32_t mem) {
+  if (!h || !actions) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  StepArgs a = base_args(h);
+  a.seed_lo = (uint32_t)seed;
+  a.seed_hi = (uint32_t)(seed >> 32);
+  a.invalid_permille = invalid_permille;
+  a.actions_out = (mem == GVEC_MEM_HOST) ? h->d_actions : actions;
+  HIPCHK(launch_agent(h->var, a, h->stream));
+  if (mem == GVEC_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(actions, h->d_actions, (size_t)h->cfg.num_envs * h->maxp * sizeof(gvec_action), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return GVEC_OK;
+}
+
+int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n, void* dst_device) {
+  if (!h || !dst_device) return GVEC_E_INVALID;
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  char* d = reinterpret_cast<char*>(dst_device);
+  const size_t hb = (size_t)n * HDR_DW * 4, rb = (size_t)n * h->row_dw * 4, ab = (size_t)n * h->army_dw * 4;
+  HIPCHK(hipMemcpyAsync(d, h->d_hdr + (size_t)env_begin * HDR_DW, hb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d + hb, h->d_rows + (size_t)env_begin * h->row_dw, rb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d + hb + rb, h->d_army + (size_t)env_begin * h->army_dw, ab, hipMemcpyDeviceToDevice, h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n, const void* src_device) {
+  if (!h || !src_device) return GVEC_E_INVALID;
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const char* d = reinterpret_cast<const char*>(src_device);
+  const size_t hb = (size_t)n * HDR_DW * 4, rb = (size_t)n * h->row_dw * 4, ab = (size_t)n * h->army_dw * 4;
+  HIPCHK(hipMemcpyAsync(h->d_hdr + (size_t)env_begin * HDR_DW, d, hb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_rows + (size_t)env_begin * h->row_dw, d + hb, rb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_army + (size_t)env_begin * h->army_dw, d + hb + rb, ab, hipMemcpyDeviceToDevice, h->stream));
+  h->legal_valid = false;
+  return GVEC_OK;
+}
+
+void* gvec_device_buffer(gvec_handle* h, int32_t which) {
+  if (!h) return nullptr;
+  switch (which) {
+    case 0: return h->d_hdr;
+    case 1: return h->d_rows;
+    case 2: return h->d_army;
+    case 3: return h->d_legal;
+    case 4: return h->d_actions;
+    case 5: return h->d_err;
+    default: return nullptr;
+  }
+}
+
+int32_t gvec_selftest(int32_t device) {
+  RET_IF(ensure_device());
+  HIPCHK(hipSetDevice(device));
+  int32_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, 16));
+  HIPCHK(hipMemset(d, 0xFF, 16));
+  hipError_t e = launch_selftest(d, nullptr);
+  int32_t out = -1;
+  if (e == hipSuccess) e = hipMemcpy(&out, d, 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_err("selftest: %s", hipGetErrorString(e));
+    return GVEC_E_HIP;
+  }
+  if (out != 0) set_err("wave-primitive self-test failed: lane %d check %d", out / 16, out % 16);
+  return out;
+}
+
+}  // extern "C"

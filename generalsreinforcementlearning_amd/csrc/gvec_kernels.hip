@@ -1,0 +1,693 @@
+// gvec_kernels.hip — HIP kernels for gfx950 (MI355X).  One wavefront per board; see
+// gvec_device.hpp for the register layout and the reference citations.
+#include "gvec_launch.hpp"
+
+#include <type_traits>
+
+namespace gvec {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// =========================================================================================
+// random agent (DESIGN.md "Synthetic inputs"; mirrored by oracle agent_env)
+// =========================================================================================
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+// index of the k-th (0-based) set bit of a wave-uniform word
+__device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
+  int pos = 0;
+#pragma unroll
+  for (int sz = 16; sz >= 1; sz >>= 1) {
+    const uint32_t c = (uint32_t)__builtin_popcount((word >> pos) & ((1u << sz) - 1u));
+    if (k >= c) {
+      k -= c;
+      pos += sz;
+    }
+  }
+  return pos;
+}
+
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
+                                             const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], uint32_t ek,
+                                             int invalid_permille, uint32_t& alo, uint32_t& ahi) {
+  constexpr int MPASS = Board<MAXP, NSLOT>::MPASS;
+  const int lane = lane_id();
+  alo = 0u;
+  ahi = 0u;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (p >= b.P || !((b.alive >> p) & 1u)) continue;
+    const uint32_t h1 = fmix32(ek + (uint32_t)b.turn * 0x9E3779B1u + (uint32_t)p * 0x7F4A7C15u + 0x165667B1u);
+    if ((h1 & 0xFFFFu) < 6554u) continue;  // no-op, p ~ 0.1
+    const bool half = (h1 >> 16) < 19661u;  // p ~ 0.3
+    const uint32_t h2 = fmix32(h1 ^ 0x68E31DA4u);
+    const uint32_t h3 = fmix32(h2 + 0xB5297A4Du);
+    int t, d;
+    if (invalid_permille > 0 && (int)mulhi32(h3, 1000u) < invalid_permille) {
+      t = (int)mulhi32(h2, (uint32_t)b.N);  // unchecked move (H5 stress)
+      d = (int)(h3 & 3u);
+    } else {
+      uint32_t sc[MPASS];
+      uint32_t total = 0u;
+#pragma unroll
+      for (int k = 0; k < MPASS; ++k) {
+        sc[k] = wave_scan_add((uint32_t)__builtin_popcount(lm[p][k])) + total;
+        total = rdlane(sc[k], 63);
+      }
+      if (total == 0u) continue;
+      uint32_t kk = mulhi32(h2, total);
+      int jj = 0;
+      uint32_t word = 0u, below = 0u;
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < MPASS; ++k) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sc[k] > kk);
+        if (!found && m) {
+          const int j = __builtin_ctzll(m);
+          word = rdlane(lm[p][k], j);
+          below = rdlane(sc[k], j) - (uint32_t)__builtin_popcount(word);
+          jj = j + 64 * k;
+          found = true;
+        }
+      }
+      const int bit = select_kth(word, kk - below);
+      const int idx = 32 * jj + bit;
+      t = idx >> 2;
+      d = idx & 3;
+    }
+    const int y = (t * b.recipW) >> 16, x = t - y * b.W;
+    const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
+    const uint32_t lo = ((uint32_t)x & 0xFFu) | (((uint32_t)y & 0xFFu) << 8) | (((uint32_t)(x + dx) & 0xFFu) << 16) |
+                        (((uint32_t)(y + dy) & 0xFFu) << 24);
+    const uint32_t hi = GVEC_ACT_VALID | (half ? GVEC_ACT_HALF : 0u);
+    alo = (lane == p) ? lo : alo;
+    ahi = (lane == p) ? hi : ahi;
+  }
+}
+
+// =========================================================================================
+// step / rollout kernel: `turns` engine turns per launch for one board per wavefront
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t* hdr, const uint32_t* rows,
+                                           const int32_t* army, uint32_t* lds, int hs, int row_dw) {
+  b.load_hdr(hdr);
+  b.tile_coords();
+  b.load_army(army);
+  b.load_rows(rows, lds, hs, row_dw);
+}
+
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  constexpr int MPASS = B::MPASS;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  uint32_t* lds = smem + wave * A.row_dw;
+  const size_t army_dw = (size_t)NSLOT * 64;
+
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.hs,
+             A.row_dw);
+
+  uint32_t lm[MAXP][MPASS];
+  bool have_lm = false, types_dirty = false;
+  uint32_t err = 0u;
+  const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
+
+  {
+    for (int k = 0; k < A.turns; ++k) {
+      if (b.hflags & HF_DONE) {
+        if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
+          // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
+          const int episode = b.episode + 1;
+          const uint32_t cs = b.cnt_steps, ca = b.cnt_abort, cd = b.cnt_done;
+          const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ ((uint32_t)episode * 0x9E3779B1u));
+          const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
+          load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * army_dw,
+                     lds, A.hs, A.row_dw);
+          b.episode = episode;
+          b.cnt_steps = cs;
+          b.cnt_abort = ca;
+          b.cnt_done = cd;
+          types_dirty = true;
+          b.legal_masks(lm);  // the mask buffer still describes the finished game
+          have_lm = true;
+          err = 0u;
+          continue;
+        }
+        err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113
+        break;
+      }
+      uint32_t alo = 0u, ahi = 0u;
+      if (A.flags & KF_AGENT) {
+        if (!have_lm) {
+          if (A.flags & KF_LMVALID) {
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+              for (int q = 0; q < MPASS; ++q) {
+                const int j = lane + 64 * q;
+                lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
+              }
+          } else {
+            b.legal_masks(lm);
+          }
+          have_lm = true;
+        }
+        agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+        if (A.actions_out && lane < A.pstride) {
+          uint2 w = make_uint2(alo, ahi);
+          reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = w;
+        }
+      } else if (lane < A.pstride) {
+        const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
+        alo = w.x;
+        ahi = w.y;
+      }
+      uint32_t ncap;
+      bool aborted;
+      err = b.turn_step(alo, ahi, A, ncap, aborted);
+      b.cnt_steps += 1u;
+      b.cnt_abort += aborted ? 1u : 0u;
+      b.cnt_done += (b.hflags & HF_DONE) ? 1u : 0u;
+      if (A.flags & (KF_AGENT | KF_EMIT)) {
+        b.legal_masks(lm);
+        have_lm = true;
+      }
+    }
+  }
+  b.last_err = err;
+
+  b.store_hdr(A.hdr + (size_t)env * HDR_DW);
+  b.store_army(A.army + (size_t)env * army_dw);
+  b.store_rows(A.rows + (size_t)env * A.row_dw, lds, A.hs, types_dirty);
+  if (A.err && lane == 0) A.err[env] = (int32_t)err;
+  if ((A.flags & KF_EMIT) && have_lm) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+      for (int q = 0; q < MPASS; ++q) {
+        const int j = lane + 64 * q;
+        if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
+      }
+  }
+}
+
+// legal masks / agent actions of the resident state (no turn is played)
+template <int MAXP, int NSLOT, bool AGENT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  constexpr int MPASS = B::MPASS;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  uint32_t* lds = smem + wave * A.row_dw;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
+             A.row_dw);
+  uint32_t lm[MAXP][MPASS];
+  b.legal_masks(lm);
+  if (AGENT) {
+    uint32_t alo = 0u, ahi = 0u;
+    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
+    if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
+  } else {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+      for (int q = 0; q < MPASS; ++q) {
+        const int j = lane + 64 * q;
+        if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
+      }
+  }
+}
+
+// =========================================================================================
+// import: planes -> resident record (gvec_reset / gvec_write_state / pool build)
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.n) return;
+  const int env = A.env_ids ? uni(A.env_ids[i]) : A.dst_begin + i;
+  uint32_t* lds = smem + wave * A.row_dw;
+  uint32_t* hdr = A.hdr + (size_t)env * HDR_DW;
+  uint32_t* rows = A.rows + (size_t)env * A.row_dw;
+  int32_t* army = A.army + (size_t)env * NSLOT * 64;
+  const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
+
+  B b;
+  if (A.fresh) {
+    b.W = A.s_width[i];
+    b.H = A.s_height[i];
+    b.P = A.s_players[i];
+    bool bad = b.W < 1 || b.W > A.max_w || b.H < 1 || b.H > A.max_h || b.P < 1 || b.P > A.max_p || b.P > MAXP;
+    if (bad) {
+      if (lane == 0) atomicExch(A.status, GVEC_E_INVALID);
+      return;
+    }
+    b.N = b.W * b.H;
+    b.recipW = (65536 + b.W - 1) / b.W;
+    b.turn = 0;
+    b.episode = 0;
+    b.hflags = A.fog ? HF_FOG : 0u;
+    b.alive = (1u << b.P) - 1u;  // initializePlayers: Alive = true (engine_initializer.go:125-143)
+    b.winner = -1;
+    b.last_err = 0u;
+    b.cnt_steps = b.cnt_abort = b.cnt_done = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      b.own[p] = b.lst[p] = b.vis[p] = 0u;
+      b.army_count[p] = 0;
+      b.gidx[p] = -1;
+    }
+    b.chg = b.vch = b.gen = b.city = b.mtn = 0u;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) b.army[s] = 0;
+    b.tile_coords();
+  } else {
+    load_board(b, hdr, rows, army, lds, A.hs, A.row_dw);
+  }
+
+  const bool row_on = lane < b.H;
+  const int row0 = lane * b.W;
+  bool bad_owner = false;
+  if (A.s_owner) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) b.own[p] = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) {
+        const int o = A.s_owner[to + row0 + x];
+        bad_owner |= (o < -1) || (o >= b.P);
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) b.own[p] |= (o == p) ? (1u << x) : 0u;
+      }
+  }
+  if (wave_any(bad_owner)) {
+    if (lane == 0) atomicExch(A.status, GVEC_E_BOARD);
+    return;
+  }
+  if (A.s_type) {
+    b.gen = b.city = b.mtn = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) {
+        const int ty = A.s_type[to + row0 + x];
+        b.gen |= (ty == GVEC_TILE_GENERAL) ? (1u << x) : 0u;
+        b.city |= (ty == GVEC_TILE_CITY) ? (1u << x) : 0u;
+        b.mtn |= (ty == GVEC_TILE_MOUNTAIN) ? (1u << x) : 0u;
+      }
+  }
+  if (A.s_visible) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) b.vis[p] = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) {
+        const uint32_t v = A.s_visible[to + row0 + x];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) b.vis[p] |= ((v >> p) & 1u) << x;
+      }
+  }
+  if (A.s_listed) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) b.lst[p] = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) {
+        const int o = A.s_listed[to + row0 + x];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) b.lst[p] |= (o == p) ? (1u << x) : 0u;
+      }
+  }
+  if (A.s_changed) {
+    b.chg = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) b.chg |= (A.s_changed[to + row0 + x] ? 1u : 0u) << x;
+  }
+  if (A.s_vis_changed) {
+    b.vch = 0u;
+    if (row_on)
+      for (int x = 0; x < b.W; ++x) b.vch |= (A.s_vis_changed[to + row0 + x] ? 1u : 0u) << x;
+  }
+  if (A.s_army) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      b.army[s] = (t < b.N) ? A.s_army[to + t] : 0;
+    }
+  }
+  if (A.s_turn) b.turn = A.s_turn[i];
+  if (A.s_done) b.hflags = A.s_done[i] ? (b.hflags | HF_DONE) : (b.hflags & ~HF_DONE);
+  if (A.s_alive) {
+    uint32_t al = 0u;
+    for (int p = 0; p < b.P; ++p) al |= (A.s_alive[po + p] ? 1u : 0u) << p;
+    b.alive = al;
+  }
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (A.s_army_count && p < b.P) b.army_count[p] = A.s_army_count[po + p];
+    if (A.s_general_idx && p < b.P) b.gidx[p] = A.s_general_idx[po + p];
+  }
+  if (A.init) b.initial_setup();
+  b.store_hdr(hdr);
+  b.store_army(army);
+  b.store_rows(rows, lds, A.hs, true);
+}
+
+// =========================================================================================
+// export: resident record -> planes (gvec_read_state / gvec_player_visibility)
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.n) return;
+  const int env = A.env_begin + i;
+  uint32_t* lds = smem + wave * A.row_dw;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
+             A.row_dw);
+  const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
+  const uint32_t special = b.gen | b.city | b.mtn;
+  uint32_t pv_plane = 0u;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) pv_plane = (p == A.vis_player) ? b.vis[p] : pv_plane;
+  const bool fog_on = (b.hflags & HF_FOG) != 0u;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int t = 64 * s + lane;
+    const bool in = t < b.N;
+    int owner = -1, listed = -1;
+    uint32_t visb = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      owner = b.gather(b.own[p], s) ? p : owner;
+      listed = b.gather(b.lst[p], s) ? p : listed;
+      visb |= b.gather(b.vis[p], s) << p;
+    }
+    const int type = b.gather(b.gen, s) ? GVEC_TILE_GENERAL
+                                        : (b.gather(b.city, s) ? GVEC_TILE_CITY : (b.gather(b.mtn, s) ? GVEC_TILE_MOUNTAIN : GVEC_TILE_NORMAL));
+    const uint32_t c = b.gather(b.chg, s), vc = b.gather(b.vch, s);
+    const uint32_t pv = b.gather(pv_plane, s), sp = b.gather(special, s);
+    if (t < A.stride) {
+      if (A.army_out) A.army_out[to + t] = in ? b.army[s] : 0;
+      if (A.owner) A.owner[to + t] = (int8_t)(in ? owner : -1);
+      if (A.type) A.type[to + t] = (uint8_t)(in ? type : 0);
+      if (A.visible) A.visible[to + t] = (uint8_t)(in ? visb : 0u);
+      if (A.listed) A.listed[to + t] = (int8_t)(in ? listed : -1);
+      if (A.changed) A.changed[to + t] = (uint8_t)(in ? c : 0u);
+      if (A.vis_changed) A.vis_changed[to + t] = (uint8_t)(in ? vc : 0u);
+      // ComputePlayerVisibilityOptimized (visibility_optimized.go:166-195)
+      if (A.pv_visible) A.pv_visible[to + t] = (uint8_t)(in ? (fog_on ? pv : 1u) : 0u);
+      if (A.pv_fog) A.pv_fog[to + t] = (uint8_t)((in && fog_on && !pv && sp) ? 1u : 0u);
+    }
+  }
+  uint32_t tcnt[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) tcnt[p] = wave_sum((uint32_t)__builtin_popcount(b.lst[p]));
+  if (lane == 0) {
+    if (A.turn) A.turn[i] = b.turn;
+    if (A.done) A.done[i] = (uint8_t)((b.hflags & HF_DONE) ? 1 : 0);
+    // Engine.GetWinner re-derives the winner from the CURRENT Alive flags (engine.go:248-263)
+    const int na = __builtin_popcount(b.alive);
+    if (A.winner) A.winner[i] = (int8_t)(((b.hflags & HF_DONE) && b.P > 1 && na == 1) ? (31 - __builtin_clz(b.alive)) : -1);
+    if (A.width) A.width[i] = b.W;
+    if (A.height) A.height[i] = b.H;
+    if (A.players) A.players[i] = b.P;
+  }
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (lane == 0 && p < A.max_p) {
+      const bool live = p < b.P;
+      if (A.alive) A.alive[po + p] = (uint8_t)(live ? ((b.alive >> p) & 1u) : 0u);
+      if (A.army_count) A.army_count[po + p] = live ? b.army_count[p] : 0;
+      if (A.tile_count) A.tile_count[po + p] = live ? (int32_t)tcnt[p] : 0;
+      if (A.general_idx) A.general_idx[po + p] = live ? b.gidx[p] : -1;
+    }
+  }
+}
+
+// =========================================================================================
+// map generator: algorithm and ratios of mapgen/generator.go:25-253 on the counter RNG.
+// One thread per board (reset-time work, sequential by nature); mirrored by ora_mapgen.
+// =========================================================================================
+struct MRng {
+  uint32_t key, ctr;
+  __device__ uint32_t draw() { return fmix32(key + (ctr++) * 0x9E3779B9u); }
+  __device__ int intn(int n) { return (int)__umulhi(draw(), (uint32_t)n); }
+};
+
+__global__ void mapgen_kernel(MapgenArgs A) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= A.n) return;
+  const int w = A.in_width ? A.in_width[i] : A.max_w, h = A.in_height ? A.in_height[i] : A.max_h;
+  const int players = A.in_players ? A.in_players[i] : A.max_p;
+  A.width[i] = w;
+  A.height[i] = h;
+  A.players[i] = players;
+  if (w < 1 || w > A.max_w || h < 1 || h > A.max_h || players < 1 || players > A.max_p) {
+    atomicExch(A.status, GVEC_E_INVALID);
+    return;
+  }
+  int32_t* army = A.army + (size_t)i * A.stride;
+  int8_t* owner = A.owner + (size_t)i * A.stride;
+  uint8_t* type = A.type + (size_t)i * A.stride;
+  const int n = w * h;
+  MRng r;
+  r.key = fmix32(env_key(A.seed_lo, A.seed_hi, (uint32_t)(A.first_index + i)) ^ 0x5BD1E995u);
+  r.ctr = 0u;
+  for (int t = 0; t < A.stride; ++t) {
+    army[t] = 0;
+    owner[t] = -1;
+    type[t] = GVEC_TILE_NORMAL;
+  }
+  // DefaultMapConfig (generator.go:25-47; config.go:198-200)
+  int spacing = 5;
+  if (spacing > w / 2 + h / 2) spacing = w / 2 + h / 2;
+  const int veins = n / 50, min_len = 3, max_len = w / 4, city_ratio = 20, city_army = 40;
+  for (int v = 0; v < veins; ++v) {  // placeMountains :77-142
+    int cx = -1, cy = -1;
+    for (int a = 0; a < 100; ++a) {
+      const int x = r.intn(w), y = r.intn(h);
+      const int idx = y * w + x;
+      if (type[idx] == GVEC_TILE_NORMAL && owner[idx] == -1) {
+        cx = x;
+        cy = y;
+        break;
+      }
+    }
+    if (cx < 0) continue;
+    type[cy * w + cx] = GVEC_TILE_MOUNTAIN;
+    int len = min_len;
+    if (max_len > min_len) len += r.intn(max_len - min_len + 1);
+    for (int k = 1; k < len; ++k) {
+      // dirs packed 2 bits each, N E S W = 0 1 2 3; rand.Shuffle = Fisher-Yates from the top (:117)
+      uint32_t dirs = 0xE4u;  // [0]=0,[1]=1,[2]=2,[3]=3
+      for (int a = 3; a > 0; --a) {
+        const int j = r.intn(a + 1);
+        const uint32_t da = (dirs >> (2 * a)) & 3u, dj = (dirs >> (2 * j)) & 3u;
+        dirs = (dirs & ~((3u << (2 * a)) | (3u << (2 * j))));
+        dirs |= (dj << (2 * a)) | (da << (2 * j));
+      }
+      uint64_t cand = 0ull;  // candidate (x,y) pairs packed 10 bits each, in shuffled-direction order
+      int nc = 0;
+      for (int j = 0; j < 4; ++j) {
+        const int d = (int)((dirs >> (2 * j)) & 3u);
+        const int nx = cx + ((d == 1) - (d == 3)), ny = cy + ((d == 2) - (d == 0));
+        if (nx >= 0 && nx < w && ny >= 0 && ny < h) {
+          const int ni = ny * w + nx;
+          if (type[ni] == GVEC_TILE_NORMAL && owner[ni] == -1) {
+            cand |= (uint64_t)(uint32_t)(nx | (ny << 5)) << (10 * nc);
+            nc++;
+          }
+        }
+      }
+      if (nc == 0) break;
+      const int pick = r.intn(nc);
+      const uint32_t c = (uint32_t)(cand >> (10 * pick)) & 1023u;
+      cx = (int)(c & 31u);
+      cy = (int)(c >> 5);
+      type[cy * w + cx] = GVEC_TILE_MOUNTAIN;
+    }
+  }
+  {  // placeCities :144-164
+    const int want = n / city_ratio, max_attempts = want * 20;
+    int placed = 0, attempts = 0;
+    while (placed < want && attempts < max_attempts) {
+      const int x = r.intn(w), y = r.intn(h);
+      const int idx = y * w + x;
+      if (owner[idx] == -1 && type[idx] == GVEC_TILE_NORMAL) {
+        type[idx] = GVEC_TILE_CITY;
+        army[idx] = city_army;
+        placed++;
+      }
+      attempts++;
+    }
+  }
+  int gx[GVEC_MAX_PLAYERS], gy[GVEC_MAX_PLAYERS];
+  for (int pid = 0; pid < players; ++pid) {  // placeGenerals :166-253
+    int placed_idx = -1;
+    for (int a = 0; a < n && placed_idx < 0; ++a) {
+      const int x = r.intn(w), y = r.intn(h);
+      const int idx = y * w + x;
+      if (owner[idx] != -1 || type[idx] != GVEC_TILE_NORMAL) continue;
+      bool ok = true;
+      for (int o = 0; o < pid; ++o) ok = ok && (abs(x - gx[o]) + abs(y - gy[o]) >= spacing);
+      if (ok) placed_idx = idx;
+    }
+    for (int idx = 0; idx < n && placed_idx < 0; ++idx) {  // fallback scan :223-250
+      if (owner[idx] != -1 || type[idx] != GVEC_TILE_NORMAL) continue;
+      const int x = idx % w, y = idx / w;
+      bool ok = true;
+      for (int o = 0; o < pid; ++o) ok = ok && (abs(x - gx[o]) + abs(y - gy[o]) >= spacing);
+      if (ok) placed_idx = idx;
+    }
+    if (placed_idx < 0) {
+      atomicExch(A.status, GVEC_E_BOARD);
+      return;
+    }
+    owner[placed_idx] = (int8_t)pid;
+    army[placed_idx] = 2;
+    type[placed_idx] = GVEC_TILE_GENERAL;
+    gx[pid] = placed_idx % w;
+    gy[pid] = placed_idx / w;
+  }
+}
+
+// =========================================================================================
+__global__ void counter_sum_kernel(const uint32_t* hdr, int32_t num_envs, unsigned long long* out) {
+  unsigned long long s0 = 0, s1 = 0, s2 = 0;
+  for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < num_envs; e += (int)(gridDim.x * blockDim.x)) {
+    const uint32_t* h = hdr + (size_t)e * HDR_DW;
+    s0 += h[H_CNT_STEPS];
+    s1 += h[H_CNT_ABORT];
+    s2 += h[H_CNT_DONE];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off);
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicAdd(out + 0, s0);
+    atomicAdd(out + 1, s1);
+    atomicAdd(out + 2, s2);
+  }
+}
+
+// device self-test of the wave primitives the engine relies on (run by tests / smoke)
+__global__ void selftest_kernel(int32_t* out) {
+  const int lane = lane_id();
+  int fail = 0;
+  const uint32_t v = (uint32_t)(lane * 3 + 1);
+  if (from_above(v) != (lane == 0 ? 0u : (uint32_t)((lane - 1) * 3 + 1))) fail = 1;
+  if (from_below(v) != (lane == 63 ? 0u : (uint32_t)((lane + 1) * 3 + 1))) fail = fail ? fail : 2;
+  uint32_t expect = 0u;
+  for (int l = 0; l <= lane; ++l) expect += (uint32_t)(l * 3 + 1);
+  if (wave_scan_add(v) != expect) fail = fail ? fail : 3;
+  if (wave_sum(v) != (uint32_t)(63 * 64 / 2 * 3 + 64)) fail = fail ? fail : 4;
+  if (bperm(4 * ((lane * 7) & 63), v) != (uint32_t)(((lane * 7) & 63) * 3 + 1)) fail = fail ? fail : 5;
+  if (spread4(0xA5u) != 0x10100101u) fail = fail ? fail : 6;
+  if (select_kth(0x80000105u, 0) != 0 || select_kth(0x80000105u, 1) != 2 || select_kth(0x80000105u, 2) != 8 ||
+      select_kth(0x80000105u, 3) != 31)
+    fail = fail ? fail : 7;
+  const unsigned long long any = __builtin_amdgcn_ballot_w64(fail != 0);
+  if (lane == 0) out[0] = any ? (int32_t)(__builtin_ctzll(any) * 16 + rdlane((uint32_t)fail, (int)__builtin_ctzll(any))) : 0;
+}
+
+// =========================================================================================
+// host-side dispatch
+// =========================================================================================
+bool pick_variant(int max_players, int tile_stride, Variant* out) {
+  static const int kP[] = {2, 4, 8};
+  static const int kS[] = {1, 2, 4, 7, 10, 16};
+  int need = (tile_stride + 63) / 64;
+  out->maxp = 0;
+  out->nslot = 0;
+  for (int p : kP)
+    if (max_players <= p) {
+      out->maxp = p;
+      break;
+    }
+  for (int s : kS)
+    if (need <= s) {
+      out->nslot = s;
+      break;
+    }
+  return out->maxp && out->nslot;
+}
+
+template <typename F>
+static hipError_t dispatch(const Variant& v, F&& f) {
+#define GVEC_CASE(P_, S_) \
+  if (v.maxp == P_ && v.nslot == S_) return f(std::integral_constant<int, P_>{}, std::integral_constant<int, S_>{});
+#define GVEC_ROW(P_) GVEC_CASE(P_, 1) GVEC_CASE(P_, 2) GVEC_CASE(P_, 4) GVEC_CASE(P_, 7) GVEC_CASE(P_, 10) GVEC_CASE(P_, 16)
+  GVEC_ROW(2) GVEC_ROW(4) GVEC_ROW(8)
+#undef GVEC_ROW
+#undef GVEC_CASE
+  return hipErrorInvalidValue;
+}
+
+static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
+static inline size_t wave_lds(int row_dw) { return (size_t)WAVES_PER_BLOCK * (size_t)row_dw * sizeof(uint32_t); }
+
+hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((step_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, true>), wave_grid(a.num_envs),
+                       dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, false>), wave_grid(a.num_envs),
+                       dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((import_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((export_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(mapgen_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_counter_sum(const uint32_t* hdr, int32_t num_envs, unsigned long long* out, hipStream_t s) {
+  int blocks = (num_envs + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(counter_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, hdr, num_envs, out);
+  return hipGetLastError();
+}
+hipError_t launch_selftest(int32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, s, out);
+  return hipGetLastError();
+}
+
+}  // namespace gvec

@@ -1,0 +1,101 @@
+// gvec_launch.hpp — host-visible launchers of the HIP kernels in gvec_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gvec_device.hpp"
+
+namespace gvec {
+
+// which compiled (MAXP, NSLOT) variant serves a handle
+struct Variant {
+  int maxp;   // 2, 4, 8
+  int nslot;  // 1, 2, 4, 7, 10, 16  (64-tile slots: ceil(max_w*max_h / 64) rounded up to a built size)
+};
+bool pick_variant(int max_players, int tile_stride, Variant* out);
+
+struct ImportArgs {
+  uint32_t* hdr;
+  uint32_t* rows;
+  int32_t* army;
+  const int32_t* env_ids;  // [n] or null (env = dst_begin + i)
+  int32_t dst_begin, n;
+  // source planes, [n][stride] / [n][max_p] / [n]; null = keep current value
+  const int32_t* s_army;
+  const int8_t* s_owner;
+  const uint8_t* s_type;
+  const uint8_t* s_visible;
+  const int8_t* s_listed;
+  const uint8_t* s_changed;
+  const uint8_t* s_vis_changed;
+  const int32_t* s_turn;
+  const uint8_t* s_done;
+  const int32_t* s_width;
+  const int32_t* s_height;
+  const int32_t* s_players;
+  const uint8_t* s_alive;
+  const int32_t* s_army_count;
+  const int32_t* s_general_idx;
+  int32_t stride, max_p, max_w, max_h, hs, row_dw;
+  uint32_t fresh;  // 1: start from a blank engine (reset); 0: poke the resident record
+  uint32_t init;   // 1: run performInitialSetup after the import
+  uint32_t fog;
+  int32_t* status;  // device word, set to a GVEC_E_* code on contract violation
+};
+
+struct ExportArgs {
+  const uint32_t* hdr;
+  const uint32_t* rows;
+  const int32_t* army;
+  int32_t env_begin, n;
+  int32_t* army_out;
+  int8_t* owner;
+  uint8_t* type;
+  uint8_t* visible;
+  int8_t* listed;
+  uint8_t* changed;
+  uint8_t* vis_changed;
+  int32_t* turn;
+  uint8_t* done;
+  int8_t* winner;
+  int32_t* width;
+  int32_t* height;
+  int32_t* players;
+  uint8_t* alive;
+  int32_t* army_count;
+  int32_t* tile_count;
+  int32_t* general_idx;
+  // ComputePlayerVisibility outputs
+  int32_t vis_player;
+  uint8_t* pv_visible;
+  uint8_t* pv_fog;
+  int32_t stride, max_p, hs, row_dw;
+};
+
+struct MapgenArgs {
+  int32_t* army;   // [n][stride]
+  int8_t* owner;
+  uint8_t* type;
+  int32_t* width;  // [n] out (what was generated)
+  int32_t* height;
+  int32_t* players;
+  const int32_t* in_width;  // [n] or null = max
+  const int32_t* in_height;
+  const int32_t* in_players;
+  int32_t n, stride, max_w, max_h, max_p, first_index;
+  uint32_t seed_lo, seed_hi;
+  int32_t* status;
+};
+
+hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s);
+hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s);
+hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s);
+hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s);
+hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s);
+hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s);
+// sums the H_CNT_* counters of all envs into out[3] (u64, device)
+hipError_t launch_counter_sum(const uint32_t* hdr, int32_t num_envs, unsigned long long* out, hipStream_t s);
+// device self-test of the wave primitives; out[0] = 0 on success else a failing check id
+hipError_t launch_selftest(int32_t* out, hipStream_t s);
+
+}  // namespace gvec

@@ -1,0 +1,211 @@
+"""VecEngine — host mirror of the reference's ``*game.Engine`` method set for B boards.
+
+Reference seam (internal/game/engine.go): NewEngine :62, Step :75, GameState :197,
+IsGameOver :198, GetWinner :248, GetLegalActionMask :271, GetChangedTiles :283,
+GetVisibilityChangedTiles :292, ComputePlayerVisibility (visibility.go:153).
+Every method is the batched form of the Go method it is named after; arrays are
+env-major numpy arrays (host) or torch-ROCm tensors passed by device pointer.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, GvecError, RolloutStats, StateView, check
+
+TILE_NORMAL, TILE_GENERAL, TILE_CITY, TILE_MOUNTAIN = 0, 1, 2, 3  # core/board.go:20-26
+ACT_VALID, ACT_HALF = 1, 2
+ERR_NAMES = {0: None, 1: "ErrInvalidCoordinates", 2: "ErrNotAdjacent", 3: "ErrNotOwned", 4: "ErrInsufficientArmy",
+             5: "ErrGameOver", 6: "ErrInvalidPlayer", 7: "ErrMoveToSelf", 8: "ErrTargetIsMountain"}  # core/errors.go:8-17
+
+ACTION_DTYPE = np.dtype([("from_x", "i1"), ("from_y", "i1"), ("to_x", "i1"), ("to_y", "i1"), ("flags", "u1"),
+                         ("reserved", "u1", (3,))])
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_STATE_SPEC = {"army": (np.int32, "tile"), "owner": (np.int8, "tile"), "type": (np.uint8, "tile"), "visible": (np.uint8, "tile"),
+               "listed": (np.int8, "tile"), "changed": (np.uint8, "tile"), "vis_changed": (np.uint8, "tile"),
+               "turn": (np.int32, "env"), "done": (np.uint8, "env"), "winner": (np.int8, "env"), "width": (np.int32, "env"),
+               "height": (np.int32, "env"), "players": (np.int32, "env"), "alive": (np.uint8, "player"),
+               "army_count": (np.int32, "player"), "tile_count": (np.int32, "player"), "general_idx": (np.int32, "player")}
+
+
+def make_actions(num_envs, max_players, moves=()):
+    """moves: iterable of (env, player, from_x, from_y, to_x, to_y, move_all) -> [B][P] action array.
+    Mirrors core.MoveAction (core/action.go:23-36); clamps coordinates like the cgo shim does."""
+    a = np.zeros((num_envs, max_players), ACTION_DTYPE)
+    for env, p, fx, fy, tx, ty, move_all in moves:
+        c = lambda v: int(max(-128, min(127, v)))
+        a[env, p] = (c(fx), c(fy), c(tx), c(ty), ACT_VALID | (0 if move_all else ACT_HALF), (0, 0, 0))
+    return a
+
+
+def unpack_legal_bits(bits, width, height):
+    """[..., mask_bytes] packed bits -> [..., W*H*4] bool in Engine.GetLegalActionMask order
+    (index (y*W+x)*4+d, d = 0 up, 1 right, 2 down, 3 left; rules/legal_moves.go:13-18)."""
+    u = np.unpackbits(np.ascontiguousarray(bits), axis=-1, bitorder="little")
+    return u[..., : width * height * 4].astype(bool)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch tensor
+
+
+class VecEngine:
+    """B independent engines stepped by one HIP launch (one wavefront per board)."""
+
+    def __init__(self, num_envs, width, height, players, fog_of_war=True, device=0, production=(1, 1, 1),
+                 normal_growth_interval=25, auto_reset=False, stream=None):
+        self.L = _lib.load()
+        cfg = Config()
+        check(self.L.gvec_config_default(C.byref(cfg)))
+        cfg.num_envs, cfg.max_width, cfg.max_height, cfg.max_players = num_envs, width, height, players
+        cfg.device, cfg.fog_of_war, cfg.auto_reset = device, int(bool(fog_of_war)), int(bool(auto_reset))
+        cfg.prod_general, cfg.prod_city, cfg.prod_normal = production
+        cfg.normal_growth_interval = normal_growth_interval
+        self.h = C.c_void_p()
+        check(self.L.gvec_create(C.byref(cfg), C.byref(self.h)), "gvec_create")
+        self.B, self.max_w, self.max_h, self.max_p = num_envs, width, height, players
+        self.stride = self.L.gvec_tile_stride(self.h)
+        self.mask_bytes = self.L.gvec_mask_bytes(self.h)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.gvec_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_stream(self, hip_stream):
+        check(self.L.gvec_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        check(self.L.gvec_synchronize(self.h))
+
+    # ---- NewEngine / EngineInitializer (engine_initializer.go:34-87) -------------------------
+    def reset(self, army, owner, type, width=None, height=None, players=None, env_ids=None):
+        """Upload boards ([n][max_w*max_h] planes, index y*W+x) and run performInitialSetup."""
+        n = len(army)
+        full = lambda v, d: np.full(n, d, np.int32) if v is None else np.ascontiguousarray(v, np.int32)
+        w, h, p = full(width, self.max_w), full(height, self.max_h), full(players, self.max_p)
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
+        army = np.ascontiguousarray(army, np.int32).reshape(n, self.stride)
+        owner = np.ascontiguousarray(owner, np.int8).reshape(n, self.stride)
+        type = np.ascontiguousarray(type, np.uint8).reshape(n, self.stride)
+        check(self.L.gvec_reset(self.h, _ptr(ids), n, _ptr(army), _ptr(owner), _ptr(type), _ptr(w), _ptr(h), _ptr(p), MEM_HOST),
+              "gvec_reset")
+
+    def reset_generated(self, seed, width=None, height=None, players=None):
+        cv = lambda v: None if v is None else np.ascontiguousarray(v, np.int32)
+        w, h, p = cv(width), cv(height), cv(players)
+        check(self.L.gvec_reset_generated(self.h, seed, _ptr(w), _ptr(h), _ptr(p)), "gvec_reset_generated")
+
+    def build_board_pool(self, pool_size, seed, width=None, height=None, players=None):
+        cv = lambda v: None if v is None else np.ascontiguousarray(v, np.int32)
+        w, h, p = cv(width), cv(height), cv(players)
+        check(self.L.gvec_build_board_pool(self.h, pool_size, seed, _ptr(w), _ptr(h), _ptr(p)), "gvec_build_board_pool")
+
+    # ---- Engine.Step (engine.go:75) --------------------------------------------------------------
+    def step(self, actions, want_mask=False):
+        """actions: [B][max_players] ACTION_DTYPE.  Returns err[B] (sentinel codes, 0 = nil error)
+        and, if want_mask, the packed post-step legal masks [B][max_players][mask_bytes]."""
+        actions = np.ascontiguousarray(actions, ACTION_DTYPE).reshape(self.B, self.max_p)
+        err = np.zeros(self.B, np.int32)
+        bits = np.zeros((self.B, self.max_p, self.mask_bytes), np.uint8) if want_mask else None
+        check(self.L.gvec_step(self.h, _ptr(actions), _ptr(err), _ptr(bits), MEM_HOST), "gvec_step")
+        return (err, bits) if want_mask else err
+
+    def step_device(self, actions_ptr, err_ptr=None, legal_ptr=None):
+        """Zero-copy form: device pointers (ints / torch tensors); enqueued, not synchronised."""
+        p = lambda v: None if v is None else (v if isinstance(v, int) else v.data_ptr())
+        check(self.L.gvec_step(self.h, p(actions_ptr), p(err_ptr), p(legal_ptr), MEM_DEVICE), "gvec_step")
+
+    # ---- Engine.GetLegalActionMask (engine.go:271-280) -----------------------------------------
+    def legal_action_mask_bits(self):
+        bits = np.zeros((self.B, self.max_p, self.mask_bytes), np.uint8)
+        check(self.L.gvec_legal_mask(self.h, _ptr(bits), MEM_HOST), "gvec_legal_mask")
+        return bits
+
+    def get_legal_action_mask(self, env, player_id):
+        """[]bool of size W*H*4 for one engine, exactly Engine.GetLegalActionMask(playerID)."""
+        st = self.game_state(env, 1, fields=("width", "height"))
+        w, h = int(st["width"][0]), int(st["height"][0])
+        if player_id < 0 or player_id >= self.max_p:
+            return np.zeros(w * h * 4, bool)  # engine.go:273-276
+        return unpack_legal_bits(self.legal_action_mask_bits()[env, player_id], w, h)
+
+    # ---- Engine.GameState / IsGameOver / GetWinner / GetChangedTiles (engine.go:197-298) ----------
+    def game_state(self, env_begin=0, n=None, fields=None):
+        n = self.B - env_begin if n is None else n
+        out, view = {}, StateView()
+        for name, (dt, kind) in _STATE_SPEC.items():
+            if fields is not None and name not in fields:
+                continue
+            shape = {"tile": (n, self.stride), "env": (n,), "player": (n, self.max_p)}[kind]
+            out[name] = np.zeros(shape, dt)
+            setattr(view, name, out[name].ctypes.data)
+        check(self.L.gvec_read_state(self.h, env_begin, n, C.byref(view), MEM_HOST), "gvec_read_state")
+        return out
+
+    def write_state(self, arrays, env_begin=0):
+        """Raw poke of engine state (what the Go tests do with e.gs.*); no init pass."""
+        view, keep = StateView(), []
+        n = None
+        for name, a in arrays.items():
+            dt, _ = _STATE_SPEC[name]
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            n = len(a) if n is None else n
+            setattr(view, name, a.ctypes.data)
+        check(self.L.gvec_write_state(self.h, env_begin, n, C.byref(view), MEM_HOST), "gvec_write_state")
+
+    def is_game_over(self):
+        return self.game_state(fields=("done",))["done"].astype(bool)
+
+    def get_winner(self):
+        return self.game_state(fields=("winner",))["winner"].astype(np.int32)
+
+    def get_changed_tiles(self):
+        return self.game_state(fields=("changed",))["changed"].astype(bool)
+
+    def get_visibility_changed_tiles(self):
+        return self.game_state(fields=("vis_changed",))["vis_changed"].astype(bool)
+
+    # ---- Engine.ComputePlayerVisibility (visibility.go:153) --------------------------------------
+    def compute_player_visibility(self, player_id):
+        vis = np.zeros((self.B, self.stride), np.uint8)
+        fog = np.zeros((self.B, self.stride), np.uint8)
+        check(self.L.gvec_player_visibility(self.h, player_id, _ptr(vis), _ptr(fog), MEM_HOST), "gvec_player_visibility")
+        return vis.astype(bool), fog.astype(bool)
+
+    # ---- synthetic random-agent rollouts ----------------------------------------------------------
+    def agent_actions(self, seed, invalid_permille=0):
+        acts = np.zeros((self.B, self.max_p), ACTION_DTYPE)
+        check(self.L.gvec_agent_actions(self.h, seed, invalid_permille, _ptr(acts), MEM_HOST), "gvec_agent_actions")
+        return acts
+
+    def rollout(self, turns, seed, invalid_permille=0, fused=True, want_stats=True):
+        st = RolloutStats()
+        check(self.L.gvec_rollout(self.h, turns, seed, invalid_permille, int(bool(fused)), C.byref(st) if want_stats else None),
+              "gvec_rollout")
+        return {"env_steps": st.env_steps, "aborted_turns": st.aborted_turns, "games_finished": st.games_finished} if want_stats else None
+
+    # ---- experience gather support -----------------------------------------------------------------
+    def state_bytes_per_env(self):
+        return self.L.gvec_state_bytes_per_env(self.h)
+
+    def export_records(self, dst_device_ptr, env_begin=0, n=None):
+        n = self.B - env_begin if n is None else n
+        check(self.L.gvec_export_records(self.h, env_begin, n, C.c_void_p(int(dst_device_ptr))), "gvec_export_records")
+
+    def import_records(self, src_device_ptr, env_begin=0, n=None):
+        n = self.B - env_begin if n is None else n
+        check(self.L.gvec_import_records(self.h, env_begin, n, C.c_void_p(int(src_device_ptr))), "gvec_import_records")
+
+    def device_buffer(self, which):
+        return self.L.gvec_device_buffer(self.h, which)

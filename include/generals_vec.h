@@ -170,8 +170,13 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n,
 int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed,
                              const int32_t* width, const int32_t* height,
                              const int32_t* players);
-/* Pool of pre-generated boards (same sizes as env i %% pool) used by auto_reset. */
-int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed);
+/* Pool of pre-generated, pre-initialised boards used by auto_reset: board j is
+ * generated with key (seed, j) and sizes width[j]/height[j]/players[j] (host arrays
+ * [pool_size], NULL = max sizes).  A finished env spends its next step being
+ * re-dealt board mulhi(fmix32(env_key(seed, env) ^ episode*0x9E3779B1), pool_size). */
+int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed,
+                              const int32_t* width, const int32_t* height,
+                              const int32_t* players);
 
 /* ---- the hot path ---------------------------------------------------------------
  * Engine.Step for every env (engine.go:75 -> turn_processor.go:29-77):
@@ -226,6 +231,20 @@ int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n,
                             void* dst_device);
 int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n,
                             const void* src_device);
+/* Zero-copy access for device consumers (torch-ROCm): the handle's resident device
+ * arrays.  which: 0 header [B][24] u32, 1 bit-rows, 2 armies, 3 legal masks
+ * [B][max_players][mask_bytes], 4 actions [B][max_players], 5 err [B]. */
+#define GVEC_BUF_HEADER  0
+#define GVEC_BUF_ROWS    1
+#define GVEC_BUF_ARMY    2
+#define GVEC_BUF_LEGAL   3
+#define GVEC_BUF_ACTIONS 4
+#define GVEC_BUF_ERR     5
+void*   gvec_device_buffer(gvec_handle* h, int32_t which);
+
+/* Runs the on-device self-test of the wave primitives (DPP shifts, scans,
+ * bpermute); 0 = pass.  Used by smoke tests on new driver / hardware revisions. */
+int32_t gvec_selftest(int32_t device);
 
 #ifdef __cplusplus
 }

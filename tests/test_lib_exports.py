@@ -1,0 +1,56 @@
+"""CPU-side checks of the product library: it builds, loads, exports every symbol the
+header declares, and refuses to compute without a GPU (no silent fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from generalsreinforcementlearning_amd.csrc import build as B  # noqa
+    return B.build(verbose=False)
+
+
+def test_header_symbols_exported(built):
+    import generalsreinforcementlearning_amd as g
+    from generalsreinforcementlearning_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "generals_vec.h")).read()
+    declared = set(re.findall(r"\b(gvec_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = g.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.gvec_abi_version() == 1
+
+
+def test_config_defaults_match_reference(built):
+    import ctypes as C
+    import generalsreinforcementlearning_amd as g
+    from generalsreinforcementlearning_amd._lib import Config
+    cfg = Config()
+    assert g.load().gvec_config_default(C.byref(cfg)) == 0
+    # internal/config/config.go:206-209, internal/game/engine_initializer.go:118
+    assert (cfg.prod_general, cfg.prod_city, cfg.prod_normal, cfg.normal_growth_interval, cfg.fog_of_war) == (1, 1, 1, 25, 1)
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import generalsreinforcementlearning_amd as g
+    with pytest.raises(g.GvecError) as ei:
+        g.VecEngine(4, 10, 10, 2)
+    assert ei.value.code == -2  # GVEC_E_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    pkg = os.path.join(ROOT, "generalsreinforcementlearning_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "generals_oracle" not in txt and "_oracle" not in txt, f
