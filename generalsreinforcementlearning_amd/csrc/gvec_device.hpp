@@ -104,6 +104,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return rdlane(wave_scan_add(v), 63); }
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// NOTE: ds_bpermute / DPP read 0 from lanes that are masked off in EXEC.  Every cross-lane
+// helper below must therefore be called under wave-uniform control flow only.
 __device__ __forceinline__ uint32_t bperm(int byte_addr, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
 }
@@ -595,7 +597,8 @@ struct Board {
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
         // :26-28 alive, :37 listed, :41 owner == pid && army > 1
-        const uint32_t can = ((alive >> p) & 1u) ? (flat_byte(lst[p] & own[p], k) & gt1) : 0u;
+        const uint32_t cb = flat_byte(lst[p] & own[p], k) & gt1;  // cross-lane: keep it unconditional
+        const uint32_t can = ((alive >> p) & 1u) ? cb : 0u;
         out[p][k] = (spread4(can) * 15u) & okn;
       }
     }

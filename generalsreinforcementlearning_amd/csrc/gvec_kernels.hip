@@ -393,8 +393,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
       listed = b.gather(b.lst[p], s) ? p : listed;
       visb |= b.gather(b.vis[p], s) << p;
     }
-    const int type = b.gather(b.gen, s) ? GVEC_TILE_GENERAL
-                                        : (b.gather(b.city, s) ? GVEC_TILE_CITY : (b.gather(b.mtn, s) ? GVEC_TILE_MOUNTAIN : GVEC_TILE_NORMAL));
+    // every gather is a cross-lane ds_bpermute: evaluate them all convergently, never inside a
+    // per-lane short-circuit (a masked-off source lane reads back as 0)
+    const uint32_t is_gen = b.gather(b.gen, s), is_city = b.gather(b.city, s), is_mtn = b.gather(b.mtn, s);
+    const int type = is_gen ? GVEC_TILE_GENERAL : (is_city ? GVEC_TILE_CITY : (is_mtn ? GVEC_TILE_MOUNTAIN : GVEC_TILE_NORMAL));
     const uint32_t c = b.gather(b.chg, s), vc = b.gather(b.vch, s);
     const uint32_t pv = b.gather(pv_plane, s), sp = b.gather(special, s);
     if (t < A.stride) {

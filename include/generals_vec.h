@@ -149,7 +149,7 @@ const char* gvec_last_error(void);
 /* sizes */
 int32_t gvec_num_envs(const gvec_handle* h);
 int32_t gvec_tile_stride(const gvec_handle* h);   /* max_width*max_height              */
-int32_t gvec_mask_bytes(const gvec_handle* h);    /* ceil(4*tile_stride/8) per player  */
+int32_t gvec_mask_bytes(const gvec_handle* h);    /* ceil(4*tile_stride/8) per player, padded to a multiple of 16 */
 int64_t gvec_state_bytes_per_env(const gvec_handle* h); /* resident device bytes / env */
 
 /* ---- reset: EngineInitializer.Initialize minus mapgen -------------------------

@@ -526,7 +526,8 @@ struct ora_batch {
 ora_batch* ora_batch_new(int32_t num_envs, int32_t max_w, int32_t max_h, int32_t max_p, const ora_params* params) {
   ora_batch* b = (ora_batch*)calloc(1, sizeof(ora_batch));
   b->num_envs = num_envs; b->max_w = max_w; b->max_h = max_h; b->max_p = max_p;
-  b->stride = max_w * max_h; b->mask_bytes = (4 * b->stride + 7) / 8;
+  b->stride = max_w * max_h;
+  b->mask_bytes = (((b->stride + 1) / 2) + 15) / 16 * 16; /* = gvec_mask_bytes(): ceil(4*stride/8) padded to 16 B */
   if (params) b->params = *params; else ora_params_default(&b->params);
   b->env = (ora_engine**)calloc((size_t)num_envs, sizeof(ora_engine*));
   b->episode = (int32_t*)calloc((size_t)num_envs, sizeof(int32_t));
