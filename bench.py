@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched Generals.io turn engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One *step* = one engine turn for every board of the batch: one launch of the HIP step
+kernel (on-device random agent sampling from the legal mask -> movement/combat ->
+eliminations -> production -> stats -> fog of war -> legal-mask emission), with the whole
+board state read from and written back to HBM.  Workload = BASELINE.json's metric config:
+20x20 boards, 4 players, fog of war on, legal mask on, 262,144 boards per GPU (weak scaling:
+every rank owns its own boards; no collective on the data path).  Finished games are re-dealt
+from a pre-generated board pool (auto-reset).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM bandwidth with
+SURVEY 8(d)'s algorithmic bytes per env-step; `cpu_baseline` times the CPU oracle (a C
+restatement of the Go engine: kind "port") on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def algorithmic_bytes(w, h, p, mask=True):
+    """state read 8 B/tile + write 8 B/tile, actions, player stats, packed masks, scalars."""
+    return 16 * w * h + 4 * p + 12 * p + (p * ((4 * w * h + 7) // 8) if mask else 0) + 16
+
+
+def cpu_baseline(w, h, p, fog, seed, budget_s=12.0):
+    """Times the CPU oracle (test infrastructure) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import _harness as H
+    import _oracle as O
+    # the GPU box gives one GPU a 16-core CPU share whatever the affinity mask says
+    cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, int(os.environ.get("GVEC_CPU_THREADS", "16"))))
+    envs = 256 * cores
+    sizes = [(w, h, p)] * envs
+    army, owner, typ, ws, hs, ps = H.gen_boards(seed, sizes, w, h)
+    ora = O.OracleBatch(envs, w, h, p, fog=fog)
+    ora.reset(army, owner, typ, ws, hs, ps)
+    ora.set_pool(1024, seed + 17)
+    # calibrate, then run ~budget_s of work
+    t0 = time.perf_counter()
+    s0 = ora.rollout(4, seed, 0, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    turns = int(max(8, min(4000, budget_s / (dt / 4))))
+    t0 = time.perf_counter()
+    steps = ora.rollout(turns, seed, 0, threads=cores)
+    dt = time.perf_counter() - t0
+    one = O.OracleBatch(256, w, h, p, fog=fog)
+    one.reset(army[:256], owner[:256], typ[:256], ws[:256], hs[:256], ps[:256])
+    t1 = time.perf_counter()
+    s1 = one.rollout(max(8, turns // 8), seed, 0, threads=1)
+    d1 = time.perf_counter() - t1
+    del s0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": s1 / d1,
+            "sample": f"{envs} boards {w}x{h} P{p} fog={'on' if fog else 'off'} x {turns} turns, oracle random agent + "
+                      f"Engine.Step restatement (no mask packing), OpenMP over boards; {dt:.1f} s of CPU work",
+            "note": "C restatement of the Go engine (oracle/generals_oracle.c); the Go toolchain is absent on this host"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=262144)
+    ap.add_argument("--width", type=int, default=20)
+    ap.add_argument("--height", type=int, default=20)
+    ap.add_argument("--players", type=int, default=4)
+    ap.add_argument("--fog", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--pool", type=int, default=4096)
+    ap.add_argument("--gather-envs", type=int, default=4096,
+                    help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import generalsreinforcementlearning_amd as g
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+
+    B, W, H, P = args.envs_per_gpu, args.width, args.height, args.players
+    eng = g.VecEngine(B, W, H, P, fog_of_war=bool(args.fog), device=local_rank, auto_reset=True, stream=stream.cuda_stream)
+    eng.reset_generated(args.seed * 1000003 + rank)
+    eng.build_board_pool(args.pool, args.seed * 7919 + rank)
+    seed = args.seed
+
+    gather_buf = None
+    side = None
+    if dist is not None and args.gather_envs > 0:
+        # the one real exchange step of the path: compact experience/state slabs -> rank 0 (StreamAggregator side)
+        rec = eng.state_bytes_per_env()
+        ge = min(args.gather_envs, B)
+        send = torch.empty(ge * rec, dtype=torch.uint8, device=dev)
+        gather_buf = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        side = torch.cuda.Stream()
+
+    def one_step(k):
+        eng.rollout(1, seed, 0, fused=False, want_stats=False)
+        if side is not None:
+            ge = min(args.gather_envs, B)
+            lo = (k * ge) % max(1, B - ge + 1)
+            eng.export_records(send.data_ptr(), lo, ge)  # on the compute stream, after this step's kernel
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                dist.gather(send, gather_buf, dst=0)
+            stream.wait_stream(side)  # send is reused next step
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    ev1.record(stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # HIP events on the launch stream
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fused = None
+    if not args.no_fused:
+        kf = max(1, min(args.steps, 64))
+        eng.rollout(kf, seed + 1, 0, fused=True, want_stats=False)
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        eng.rollout(kf, seed + 2, 0, fused=True, want_stats=False)
+        f1.record(stream)
+        torch.cuda.synchronize()
+        fused = {"turns_per_launch": kf, "env_steps_per_s_per_gpu": B * kf / (f0.elapsed_time(f1) / 1e3),
+                 "note": "same turns with board state kept in registers/LDS across one launch (gvec_rollout fused=1)"}
+
+    if rank == 0:
+        n = world
+        abytes = algorithmic_bytes(W, H, P, True)
+        achieved = abytes * B / (kernel_ms / 1e3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("envs") == B and rec.get("board") == [W, H, P]:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (whole node), 20x20 4P fog-on, bit-exact vs Go ref",
+            "value": n * B * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{B} boards/GPU x {W}x{H} {P}P fog-{'on' if args.fog else 'off'} + legal mask, on-device random "
+                                   f"agent, auto-reset pool {args.pool}, 1 turn per launch",
+                       "envs_per_gpu": B, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
+                       "gather_envs_per_step": (args.gather_envs if n > 1 else 0)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "gvec::step_kernel<4,7>", "algorithmic_bytes_per_env_step": abytes,
+                         "units_per_launch": B, "kernel_ms": kernel_ms},
+        }
+        if fused:
+            out["fused_rollout"] = fused
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, P, bool(args.fog), args.seed)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
