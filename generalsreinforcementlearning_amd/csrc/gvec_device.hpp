@@ -34,7 +34,7 @@ constexpr int HDR_DW = 24;
 enum : int {
   H_TURN = 0,     // GameState.Turn
   H_DIMS = 1,     // W | H<<8 | P<<16 | flags<<24   (flags: bit0 Engine.gameOver, bit1 FogOfWarEnabled)
-  H_STATUS = 2,   // alive bits | (winner+1)<<8 | last err<<16
+  H_STATUS = 2,   // alive bits | last err<<16
   H_EPISODE = 3,  // re-deal counter (auto-reset)
   H_ARMYCNT = 4,  // [8] Player.ArmyCount
   H_GIDX = 12,    // [8] Player.GeneralIdx
@@ -153,11 +153,13 @@ struct Board {
   int xsh[NSLOT];   // x of that tile
   // flat-byte domain: lane j (+64*pass) assembles bits [8j, 8j+8) of a plane's row-major bit string
   int fb_ysel[MPASS], fb_x0[MPASS];
+  // header: lane k holds header dword k (Player.ArmyCount / GeneralIdx, counters, ... live here;
+  // only what the turn logic branches on is also kept wave-uniform below)
+  uint32_t hv;
+  int32_t* larmy;  // LDS shadow of the armies during the action phase: tile t at larmy[t]
   // wave-uniform
-  int W, H, P, N, turn, episode, recipW;
-  uint32_t alive, hflags, last_err, cnt_steps, cnt_abort, cnt_done;
-  int winner;
-  int army_count[MAXP], gidx[MAXP];
+  int W, H, P, N, turn, recipW;
+  uint32_t alive, hflags;
 
   // ---------------------------------------------------------------------------------------
   __device__ __forceinline__ void tile_coords() {
@@ -182,47 +184,27 @@ struct Board {
   // ---- load / store ---------------------------------------------------------------------
   __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
     const int lane = lane_id();
-    uint32_t hv = (lane < HDR_DW) ? hdr_env[lane] : 0u;
+    hv = (lane < HDR_DW) ? hdr_env[lane] : 0u;
     turn = (int)rdlane(hv, H_TURN);
-    uint32_t dims = rdlane(hv, H_DIMS);
+    const uint32_t dims = rdlane(hv, H_DIMS);
     W = (int)(dims & 0xFFu);
     H = (int)((dims >> 8) & 0xFFu);
     P = (int)((dims >> 16) & 0xFFu);
     hflags = dims >> 24;
     N = W * H;
-    uint32_t st = rdlane(hv, H_STATUS);
-    alive = st & 0xFFu;
-    winner = (int)((st >> 8) & 0xFFu) - 1;
-    last_err = (st >> 16) & 0xFFu;
-    episode = (int)rdlane(hv, H_EPISODE);
+    alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
-    cnt_steps = rdlane(hv, H_CNT_STEPS);
-    cnt_abort = rdlane(hv, H_CNT_ABORT);
-    cnt_done = rdlane(hv, H_CNT_DONE);
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      army_count[p] = (int)rdlane(hv, H_ARMYCNT + p);
-      gidx[p] = (int)rdlane(hv, H_GIDX + p);
-    }
   }
+  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (lane_id() == k) ? v : hv; }
+  __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
 
-  __device__ __forceinline__ void store_hdr(uint32_t* hdr_env) const {
+  __device__ __forceinline__ void store_hdr(uint32_t* hdr_env, uint32_t last_err) {
     const int lane = lane_id();
-    uint32_t v = 0u;
-    v = (lane == H_TURN) ? (uint32_t)turn : v;
-    v = (lane == H_DIMS) ? ((uint32_t)W | ((uint32_t)H << 8) | ((uint32_t)P << 16) | (hflags << 24)) : v;
-    v = (lane == H_STATUS) ? (alive | ((uint32_t)(winner + 1) << 8) | (last_err << 16)) : v;
-    v = (lane == H_EPISODE) ? (uint32_t)episode : v;
-    v = (lane == H_RECIPW) ? (uint32_t)recipW : v;
-    v = (lane == H_CNT_STEPS) ? cnt_steps : v;
-    v = (lane == H_CNT_ABORT) ? cnt_abort : v;
-    v = (lane == H_CNT_DONE) ? cnt_done : v;
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      v = (lane == H_ARMYCNT + p) ? (uint32_t)army_count[p] : v;
-      v = (lane == H_GIDX + p) ? (uint32_t)gidx[p] : v;
-    }
-    if (lane < HDR_DW) hdr_env[lane] = v;
+    hdr_set(H_TURN, (uint32_t)turn);
+    hdr_set(H_DIMS, (uint32_t)W | ((uint32_t)H << 8) | ((uint32_t)P << 16) | (hflags << 24));
+    hdr_set(H_STATUS, alive | (last_err << 16));
+    hdr_set(H_RECIPW, (uint32_t)recipW);
+    if (lane < HDR_DW) hdr_env[lane] = hv;
   }
 
   // rows: HBM --(flat dwordx4)--> LDS --(ds_read_b32, lane = row)--> registers
@@ -292,24 +274,24 @@ struct Board {
   }
 
   // ---- uniform tile access ----------------------------------------------------------------
-  // (readlane of every slot, then a scalar select: a select chain over army[i] itself is
-  // rewritten by LLVM into one load through a selected ADDRESS, which demotes the whole
-  // board to scratch memory)
-  __device__ __forceinline__ int army_get(int t) const {
-    const int s = t >> 6, l = t & 63;
-    int r = 0;
+  // During the action phase the armies live in an LDS shadow: a wave-uniform tile index is one
+  // broadcast ds_read / one single-lane ds_write instead of an NSLOT-way register select chain
+  // (which costs ~3 scalar instructions per slot on the CU's single scalar pipe).
+  __device__ __forceinline__ void army_to_lds() {
+    const int lane = lane_id();
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int v = __builtin_amdgcn_readlane(army[i], l);
-      r = (s == i) ? v : r;
-    }
-    return r;
+    for (int s = 0; s < NSLOT; ++s) larmy[64 * s + lane] = army[s];
+    wave_lds_fence();
   }
-  __device__ __forceinline__ void army_set(int t, int val) {
-    const int s = t >> 6, l = t & 63;
-    const bool me = lane_id() == l;
+  __device__ __forceinline__ void army_from_lds() {
+    const int lane = lane_id();
+    wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) army[i] = (me && s == i) ? val : army[i];
+    for (int s = 0; s < NSLOT; ++s) army[s] = larmy[64 * s + lane];
+  }
+  __device__ __forceinline__ int army_get(int t) const { return uni(larmy[t]); }
+  __device__ __forceinline__ void army_set(int t, int val) {
+    if (lane_id() == 0) larmy[t] = val;
   }
   __device__ __forceinline__ bool bit_at(uint32_t plane, int x, int y) const { return (rdlane(plane, y) >> x) & 1u; }
 
@@ -323,19 +305,19 @@ struct Board {
   // bits [8j, 8j+8) of the plane's row-major bit string (j = lane + 64*pass)
   __device__ __forceinline__ uint32_t flat_byte(uint32_t plane, int pass) const {
     if (W >= 8) {  // 8 consecutive tiles touch at most two rows
-      uint32_t r0 = bperm(fb_ysel[pass], plane), r1 = bperm(fb_ysel[pass] + 4, plane);
-      uint64_t two = (uint64_t)r0 | ((uint64_t)r1 << W);
+      const uint32_t r0 = bperm(fb_ysel[pass], plane), r1 = bperm(fb_ysel[pass] + 4, plane);
+      const uint64_t two = (uint64_t)r0 | ((uint64_t)r1 << W);
       return (uint32_t)(two >> fb_x0[pass]) & 0xFFu;
     }
-    uint32_t out = 0u;  // tiny boards (tests): bit by bit
-    const int j = lane_id() + 64 * pass;
-    for (int b = 0; b < 8; ++b) {
-      int f = 8 * j + b;
-      int y = (f * recipW) >> 16;
-      int x = f - y * W;
-      out |= ((bperm(4 * (y < 63 ? y : 63), plane) >> x) & 1u) << b;
+    // narrow boards (W < 8, reference tests): up to 9 rows contribute; wave-uniform trip count
+    uint64_t acc = 0ull;
+    const int nr = (8 + W - 1) / W + 1;
+    for (int r = 0; r < nr; ++r) {
+      int a = fb_ysel[pass] + 4 * r;
+      a = a < 252 ? a : 252;  // lane 63 holds no board row
+      acc |= (uint64_t)bperm(a, plane) << (r * W);
     }
-    return out;
+    return (uint32_t)(acc >> fb_x0[pass]) & 0xFFu;
   }
 
   // ---- 3x3 / 5x5 dilations (visibility_optimized.go:9-13, :104-105) -----------------------
@@ -389,7 +371,7 @@ struct Board {
     alive = 0u;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      army_count[p] = (int)wave_sum((uint32_t)acc[p]);
+      hdr_set(H_ARMYCNT + p, wave_sum((uint32_t)acc[p]));
       // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two
       // or more generals that order depends on Go map iteration.  Here: the highest tile index.
       const uint32_t g = lst[p] & gen;
@@ -400,7 +382,7 @@ struct Board {
         const uint32_t r = rdlane(g, y);
         gi = y * W + (31 - __builtin_clz(r));
       }
-      gidx[p] = gi;
+      hdr_set(H_GIDX + p, (uint32_t)gi);
       alive |= (gi >= 0) ? (1u << p) : 0u;  // :52-54 / :133-135
     }
   }
@@ -433,48 +415,71 @@ struct Board {
     const int na = __builtin_popcount(alive);
     const bool over = (P > 1) ? (na <= 1) : (na == 0);  // originalPlayers == len(Players)
     hflags = over ? (hflags | HF_DONE) : (hflags & ~HF_DONE);
-    winner = (over && na == 1) ? (31 - __builtin_clz(alive)) : -1;
+    // the winner is re-derived from Alive on read-back, like Engine.GetWinner (engine.go:248-263)
   }
 
-  // ---- one player's move: MoveAction.Validate + core.ApplyMoveAction ------------------------
-  // (core/action.go:56-105, core/movement.go:23-89) inside ActionProcessor.ProcessActions
-  // (processor/action_processor.go:36-99).  `orders` packs core.ProcessCaptures' output
-  // (movement.go:100-118): byte k = victim | new_owner << 4.
-  template <int PID>
-  __device__ __forceinline__ void apply_action(uint32_t a_lo, uint32_t a_hi, uint32_t& first_err, uint64_t& orders,
-                                               int& n_orders, uint32_t& elim_seen, uint32_t& ncap) {
-    if (!(a_hi & GVEC_ACT_VALID)) return;  // nil action
-    if (!((alive >> PID) & 1u)) return;     // action_processor.go:56-60 (Alive as last written, H2)
-    const int fx = (int)(int8_t)(a_lo & 0xFFu), fy = (int)(int8_t)((a_lo >> 8) & 0xFFu);
-    const int tx = (int)(int8_t)((a_lo >> 16) & 0xFFu), ty = (int)(int8_t)(a_lo >> 24);
+  // ---- the action phase: ActionProcessor.ProcessActions (processor/action_processor.go:36-99) ----
+  // Everything about a move that does not depend on the board as modified by lower player ids is
+  // computed for all players at once on lanes (lane p = player p): coordinate unpack, bounds,
+  // same-tile and adjacency checks of MoveAction.Validate (core/action.go:58-76), tile indices.
+  struct ActVec {
+    uint32_t meta;  // bits 0-3 static Validate code, bit 4 present (non-nil), bit 5 half
+    uint32_t xy;    // fx | fy<<8 | tx<<16 | ty<<24 (as submitted)
+    int ft, tt;     // y*W + x of source / target
+  };
+  __device__ __forceinline__ ActVec prevalidate(uint32_t alo, uint32_t ahi) const {
+    ActVec v;
+    const int fx = (int)(int8_t)(alo & 0xFFu), fy = (int)(int8_t)((alo >> 8) & 0xFFu);
+    const int tx = (int)(int8_t)((alo >> 16) & 0xFFu), ty = (int)(int8_t)(alo >> 24);
+    const bool inb = fx >= 0 && fx < W && fy >= 0 && fy < H && tx >= 0 && tx < W && ty >= 0 && ty < H;
+    const int dx = fx - tx, dy = fy - ty;
+    const int md = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
     uint32_t code = 0u;
-    int fa = 0;
-    const bool inb_f = fx >= 0 && fx < W && fy >= 0 && fy < H, inb_t = tx >= 0 && tx < W && ty >= 0 && ty < H;
-    if (!inb_f || !inb_t) code = GVEC_ERR_INVALID_COORDINATES;       // action.go:58-64
-    else if (fx == tx && fy == ty) code = GVEC_ERR_MOVE_TO_SELF;    // :67-69
-    else {
-      const int dx = fx - tx, dy = fy - ty;
-      const bool adj = (dx == 0 && (dy == 1 || dy == -1)) || (dy == 0 && (dx == 1 || dx == -1));
-      if (!adj) code = GVEC_ERR_NOT_ADJACENT;  // :72-76
-      else if (!bit_at(own[PID], fx, fy)) code = GVEC_ERR_NOT_OWNED;  // :82-84
-      else {
-        fa = army_get(fy * W + fx);
-        if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;                // :87-89
-        else if (bit_at(mtn, tx, ty)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;  // :96-98
-      }
+    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;        // action.go:72-76 (orthogonal, one step)
+    code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;        // :67-69
+    code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;    // :58-64
+    v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
+    v.xy = alo;
+    v.ft = fy * W + fx;
+    v.tt = ty * W + tx;
+    return v;
+  }
+
+  // The state-dependent rest of Validate + core.ApplyMoveAction (core/movement.go:23-89) for
+  // player PID, wave-uniform.  `orders` packs core.ProcessCaptures' output (movement.go:100-118):
+  // byte k = victim | new_owner << 4.
+  template <int PID>
+  __device__ __forceinline__ void apply_action(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
+                                               uint32_t& elim_seen) {
+    const uint32_t m = rdlane(av.meta, PID);
+    if (!(m & 16u)) return;              // nil action
+    if (!((alive >> PID) & 1u)) return;  // action_processor.go:56-60 (Alive as last written, H2)
+    uint32_t code = m & 15u;
+    int fa = 0, ta = 0, fx = 0, fy = 0, tx = 0, ty = 0, ft = 0, tt = 0;
+    if (!code) {
+      const uint32_t a = rdlane(av.xy, PID);
+      fx = (int)(a & 0xFFu);
+      fy = (int)((a >> 8) & 0xFFu);
+      tx = (int)((a >> 16) & 0xFFu);
+      ty = (int)(a >> 24);
+      ft = (int)rdlane((uint32_t)av.ft, PID);
+      tt = (int)rdlane((uint32_t)av.tt, PID);
+      fa = army_get(ft);
+      ta = army_get(tt);
+      if (!bit_at(own[PID], fx, fy)) code = GVEC_ERR_NOT_OWNED;           // action.go:82-84
+      else if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;                // :87-89
+      else if (bit_at(mtn, tx, ty)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;   // :96-98
     }
     if (code) {  // action_processor.go:66-77: remember the FIRST error, keep going
       first_err = first_err ? first_err : code;
       return;
     }
-    int n = (a_hi & GVEC_ACT_HALF) ? (fa / 2) : (fa - 1);  // movement.go:40-49
+    int n = (m & 32u) ? (fa / 2) : (fa - 1);  // movement.go:40-49
     n = (n == 0) ? 1 : n;
     const int lane = lane_id();
     const uint32_t fbit = (lane == fy) ? (1u << fx) : 0u, tbit = (lane == ty) ? (1u << tx) : 0u;
-    army_set(fy * W + fx, fa - n);  // :54
-    chg |= fbit | tbit;             // :57-60
-    const int tt = ty * W + tx;
-    const int ta = army_get(tt);
+    army_set(ft, fa - n);  // :54
+    chg |= fbit | tbit;    // :57-60
     if (bit_at(own[PID], tx, ty)) {  // :62-66 own tile: consolidate
       army_set(tt, ta + n);
     } else if (n > ta) {  // :69-82 capture (ties favour the defender)
@@ -487,7 +492,6 @@ struct Board {
       own[PID] |= tbit;
       army_set(tt, n - ta);
       vch |= tbit;  // action_processor.go:84-86
-      ncap++;
       // movement.go:105-108
       if (bit_at(gen, tx, ty) && prev >= 0 && !((elim_seen >> prev) & 1u)) {
         orders |= (uint64_t)((uint32_t)prev | ((uint32_t)PID << 4)) << (8 * n_orders);
@@ -500,12 +504,11 @@ struct Board {
   }
 
   template <int PID>
-  __device__ __forceinline__ void act_chain(uint32_t acts_lo, uint32_t acts_hi, uint32_t& first_err, uint64_t& orders,
-                                            int& n_orders, uint32_t& elim_seen, uint32_t& ncap) {
+  __device__ __forceinline__ void act_chain(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
+                                            uint32_t& elim_seen) {
     if constexpr (PID < MAXP) {
-      if (PID < P)
-        apply_action<PID>(rdlane(acts_lo, PID), rdlane(acts_hi, PID), first_err, orders, n_orders, elim_seen, ncap);
-      act_chain<PID + 1>(acts_lo, acts_hi, first_err, orders, n_orders, elim_seen, ncap);
+      if (PID < P) apply_action<PID>(av, first_err, orders, n_orders, elim_seen);
+      act_chain<PID + 1>(av, first_err, orders, n_orders, elim_seen);
     }
   }
 
@@ -520,9 +523,9 @@ struct Board {
       for (int q = 0; q < MAXP; ++q) {
         own[q] = (q == v) ? (own[q] & ~tiles) : own[q];
         own[q] = (q == nw) ? (own[q] | tiles) : own[q];
-        gidx[q] = (q == v) ? -1 : gidx[q];  // :141
       }
-      chg |= tiles;  // :133-134
+      hdr_set(H_GIDX + v, 0xFFFFFFFFu);  // :141 GeneralIdx = -1
+      chg |= tiles;                      // :133-134
       vch |= tiles;
       alive &= ~(1u << v);  // :140
     }
@@ -530,21 +533,24 @@ struct Board {
 
   // ---- TurnProcessor.ProcessTurn (turn_processor.go:29-77) ----------------------------------
   // acts_lo/hi: lane p holds player p's gvec_action words.  Returns the per-env error code.
-  __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, uint32_t& ncap_out,
-                                                bool& aborted) {
+  // Precondition: the caller has checked Engine.gameOver (validateGameState :95-113).
+  __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, bool& aborted) {
     aborted = false;
-    ncap_out = 0u;
-    if (hflags & HF_DONE) return GVEC_ERR_GAME_OVER;  // validateGameState :95-113
-    turn++;                                           // initializeTurn :124-135
+    turn++;  // initializeTurn :124-135
     update_fog();
     chg = 0u;
     vch = 0u;
-    uint32_t first_err = 0u, elim_seen = 0u, ncap = 0u;
+    uint32_t first_err = 0u, elim_seen = 0u;
     uint64_t orders = 0ull;
     int n_orders = 0;
     // Engine.processActions (engine.go:80-115): PlayerID order == slot order (sort.Slice :39-41)
-    act_chain<0>(acts_lo, acts_hi, first_err, orders, n_orders, elim_seen, ncap);
-    ncap_out = ncap;
+    const ActVec av = prevalidate(acts_lo, acts_hi);
+    const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
+    if (present) {  // a turn where nobody moves touches no army
+      army_to_lds();
+      act_chain<0>(av, first_err, orders, n_orders, elim_seen);
+      army_from_lds();
+    }
     if (n_orders > 0) {  // engine.go:101-109
       eliminate(orders, n_orders);
       update_stats();

@@ -13,77 +13,69 @@ constexpr int WAVES_PER_BLOCK = 4;
 // =========================================================================================
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
-// index of the k-th (0-based) set bit of a wave-uniform word
+// index of the k-th (0-based) set bit of a wave-uniform word: lane i counts the set bits in
+// positions 0..i; the first lane whose count exceeds k names the bit
 __device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
-  int pos = 0;
-#pragma unroll
-  for (int sz = 16; sz >= 1; sz >>= 1) {
-    const uint32_t c = (uint32_t)__builtin_popcount((word >> pos) & ((1u << sz) - 1u));
-    if (k >= c) {
-      k -= c;
-      pos += sz;
-    }
-  }
-  return pos;
+  const uint32_t c = (uint32_t)__builtin_popcount(word & (0xFFFFFFFFu >> (31 - (lane_id() & 31))));
+  return (int)__builtin_ctz((uint32_t)__builtin_amdgcn_ballot_w64(c > k));
 }
 
+// All hashing / coordinate arithmetic runs on lanes (lane p = player p); only the choice of the
+// k-th legal move needs a wave-wide scan per player.
 template <int MAXP, int NSLOT>
 __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
                                              const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], uint32_t ek,
                                              int invalid_permille, uint32_t& alo, uint32_t& ahi) {
   constexpr int MPASS = Board<MAXP, NSLOT>::MPASS;
   const int lane = lane_id();
-  alo = 0u;
-  ahi = 0u;
+  const uint32_t h1 = fmix32(ek + (uint32_t)b.turn * 0x9E3779B1u + (uint32_t)lane * 0x7F4A7C15u + 0x165667B1u);
+  const uint32_t h2 = fmix32(h1 ^ 0x68E31DA4u);
+  const uint32_t h3 = fmix32(h2 + 0xB5297A4Du);
+  bool act = lane < b.P && ((b.alive >> lane) & 1u) && !((h1 & 0xFFFFu) < 6554u);  // no-op with p ~ 0.1
+  const bool half = (h1 >> 16) < 19661u;                                             // p ~ 0.3
+  const bool inv = invalid_permille > 0 && (int)mulhi32(h3, 1000u) < invalid_permille;
+  int t = (int)mulhi32(h2, (uint32_t)b.N);  // unchecked move (H5 stress) unless replaced below
+  int d = (int)(h3 & 3u);
+  const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64(act && !inv);
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
-    if (p >= b.P || !((b.alive >> p) & 1u)) continue;
-    const uint32_t h1 = fmix32(ek + (uint32_t)b.turn * 0x9E3779B1u + (uint32_t)p * 0x7F4A7C15u + 0x165667B1u);
-    if ((h1 & 0xFFFFu) < 6554u) continue;  // no-op, p ~ 0.1
-    const bool half = (h1 >> 16) < 19661u;  // p ~ 0.3
-    const uint32_t h2 = fmix32(h1 ^ 0x68E31DA4u);
-    const uint32_t h3 = fmix32(h2 + 0xB5297A4Du);
-    int t, d;
-    if (invalid_permille > 0 && (int)mulhi32(h3, 1000u) < invalid_permille) {
-      t = (int)mulhi32(h2, (uint32_t)b.N);  // unchecked move (H5 stress)
-      d = (int)(h3 & 3u);
-    } else {
-      uint32_t sc[MPASS];
-      uint32_t total = 0u;
+    if (!((need >> p) & 1u)) continue;
+    uint32_t sc[MPASS];
+    uint32_t total = 0u;
 #pragma unroll
-      for (int k = 0; k < MPASS; ++k) {
-        sc[k] = wave_scan_add((uint32_t)__builtin_popcount(lm[p][k])) + total;
-        total = rdlane(sc[k], 63);
-      }
-      if (total == 0u) continue;
-      uint32_t kk = mulhi32(h2, total);
-      int jj = 0;
-      uint32_t word = 0u, below = 0u;
-      bool found = false;
-#pragma unroll
-      for (int k = 0; k < MPASS; ++k) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(sc[k] > kk);
-        if (!found && m) {
-          const int j = __builtin_ctzll(m);
-          word = rdlane(lm[p][k], j);
-          below = rdlane(sc[k], j) - (uint32_t)__builtin_popcount(word);
-          jj = j + 64 * k;
-          found = true;
-        }
-      }
-      const int bit = select_kth(word, kk - below);
-      const int idx = 32 * jj + bit;
-      t = idx >> 2;
-      d = idx & 3;
+    for (int k = 0; k < MPASS; ++k) {
+      sc[k] = wave_scan_add((uint32_t)__builtin_popcount(lm[p][k])) + total;
+      total = rdlane(sc[k], 63);
     }
-    const int y = (t * b.recipW) >> 16, x = t - y * b.W;
-    const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
-    const uint32_t lo = ((uint32_t)x & 0xFFu) | (((uint32_t)y & 0xFFu) << 8) | (((uint32_t)(x + dx) & 0xFFu) << 16) |
-                        (((uint32_t)(y + dy) & 0xFFu) << 24);
-    const uint32_t hi = GVEC_ACT_VALID | (half ? GVEC_ACT_HALF : 0u);
-    alo = (lane == p) ? lo : alo;
-    ahi = (lane == p) ? hi : ahi;
+    if (total == 0u) {  // no legal move: no action
+      act = act && lane != p;
+      continue;
+    }
+    const uint32_t kk = mulhi32(rdlane(h2, p), total);
+    int jj = 0;
+    uint32_t word = 0u, below = 0u;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < MPASS; ++k) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(sc[k] > kk);
+      if (!found && m) {
+        const int j = __builtin_ctzll(m);
+        word = rdlane(lm[p][k], j);
+        below = rdlane(sc[k], j) - (uint32_t)__builtin_popcount(word);
+        jj = j + 64 * k;
+        found = true;
+      }
+    }
+    const int idx = 32 * jj + select_kth(word, kk - below);
+    t = (lane == p) ? (idx >> 2) : t;
+    d = (lane == p) ? (idx & 3) : d;
   }
+  const int y = (t * b.recipW) >> 16, x = t - y * b.W;
+  const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
+  const uint32_t lo = ((uint32_t)x & 0xFFu) | (((uint32_t)y & 0xFFu) << 8) | (((uint32_t)(x + dx) & 0xFFu) << 16) |
+                      (((uint32_t)(y + dy) & 0xFFu) << 24);
+  alo = act ? lo : 0u;
+  ahi = act ? (GVEC_ACT_VALID | (half ? GVEC_ACT_HALF : 0u)) : 0u;
 }
 
 // =========================================================================================
@@ -98,6 +90,14 @@ __device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t
   b.load_rows(rows, lds, hs, row_dw);
 }
 
+// per-wave LDS: [row_dw] staging of the bit-rows, then [NSLOT*64] army shadow
+template <int NSLOT>
+__device__ __forceinline__ uint32_t* wave_lds(uint32_t* smem, int wave, int row_dw, int32_t** larmy) {
+  uint32_t* base = smem + (size_t)wave * (size_t)(row_dw + NSLOT * 64);
+  *larmy = reinterpret_cast<int32_t*>(base + row_dw);
+  return base;
+}
+
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -106,87 +106,84 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + wave * A.row_dw;
-  const size_t army_dw = (size_t)NSLOT * 64;
-
   B b;
+  uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
+  const size_t army_dw = (size_t)NSLOT * 64;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.hs,
              A.row_dw);
 
   uint32_t lm[MAXP][MPASS];
-  bool have_lm = false, types_dirty = false;
-  uint32_t err = 0u;
+  const bool agent = (A.flags & KF_AGENT) != 0u, emit = (A.flags & KF_EMIT) != 0u;
+  bool lm_valid = false, types_dirty = false;
+  if (agent && (A.flags & KF_LMVALID)) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+      for (int q = 0; q < MPASS; ++q) {
+        const int j = lane + 64 * q;
+        lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
+      }
+    lm_valid = true;
+  }
+  uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
 
-  {
-    for (int k = 0; k < A.turns; ++k) {
-      if (b.hflags & HF_DONE) {
-        if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
-          // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
-          const int episode = b.episode + 1;
-          const uint32_t cs = b.cnt_steps, ca = b.cnt_abort, cd = b.cnt_done;
-          const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ ((uint32_t)episode * 0x9E3779B1u));
-          const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
-          load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * army_dw,
-                     lds, A.hs, A.row_dw);
-          b.episode = episode;
-          b.cnt_steps = cs;
-          b.cnt_abort = ca;
-          b.cnt_done = cd;
-          types_dirty = true;
-          b.legal_masks(lm);  // the mask buffer still describes the finished game
-          have_lm = true;
-          err = 0u;
-          continue;
-        }
-        err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113
-        break;
-      }
-      uint32_t alo = 0u, ahi = 0u;
-      if (A.flags & KF_AGENT) {
-        if (!have_lm) {
-          if (A.flags & KF_LMVALID) {
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-              for (int q = 0; q < MPASS; ++q) {
-                const int j = lane + 64 * q;
-                lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
-              }
-          } else {
-            b.legal_masks(lm);
-          }
-          have_lm = true;
-        }
-        agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
-        if (A.actions_out && lane < A.pstride) {
-          uint2 w = make_uint2(alo, ahi);
-          reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = w;
-        }
-      } else if (lane < A.pstride) {
-        const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
-        alo = w.x;
-        ahi = w.y;
-      }
-      uint32_t ncap;
-      bool aborted;
-      err = b.turn_step(alo, ahi, A, ncap, aborted);
-      b.cnt_steps += 1u;
-      b.cnt_abort += aborted ? 1u : 0u;
-      b.cnt_done += (b.hflags & HF_DONE) ? 1u : 0u;
-      if (A.flags & (KF_AGENT | KF_EMIT)) {
-        b.legal_masks(lm);
-        have_lm = true;
-      }
+  for (int k = 0;; ++k) {
+    // the masks of the CURRENT state: input of the agent, and the output after the last turn
+    if (!lm_valid && (agent || emit) && (agent || k == A.turns)) {
+      b.legal_masks(lm);
+      lm_valid = true;
     }
+    if (k >= A.turns) break;
+    if (b.hflags & HF_DONE) {
+      if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
+        // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
+        const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
+        const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
+        const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
+        const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
+        load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * army_dw, lds,
+                   A.hs, A.row_dw);
+        b.hdr_set(H_EPISODE, episode);
+        b.hdr_set(H_CNT_STEPS, cs);
+        b.hdr_set(H_CNT_ABORT, ca);
+        b.hdr_set(H_CNT_DONE, cd);
+        types_dirty = true;
+        lm_valid = false;
+        err = 0u;
+        continue;
+      }
+      err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
+      k = A.turns - 1;           // nothing more will happen in this launch
+      continue;
+    }
+    uint32_t alo = 0u, ahi = 0u;
+    if (agent) {
+      agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+      if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
+    } else if (lane < A.pstride) {
+      const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
+      alo = w.x;
+      ahi = w.y;
+    }
+    bool aborted;
+    err = b.turn_step(alo, ahi, A, aborted);
+    lm_valid = false;
+    n_steps += 1u;
+    n_abort += aborted ? 1u : 0u;
+    n_done += (b.hflags & HF_DONE) ? 1u : 0u;
   }
-  b.last_err = err;
-
-  b.store_hdr(A.hdr + (size_t)env * HDR_DW);
+  {
+    const uint32_t cs = b.hdr_get(H_CNT_STEPS) + n_steps, ca = b.hdr_get(H_CNT_ABORT) + n_abort, cd = b.hdr_get(H_CNT_DONE) + n_done;
+    b.hdr_set(H_CNT_STEPS, cs);
+    b.hdr_set(H_CNT_ABORT, ca);
+    b.hdr_set(H_CNT_DONE, cd);
+  }
+  b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_army(A.army + (size_t)env * army_dw);
   b.store_rows(A.rows + (size_t)env * A.row_dw, lds, A.hs, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
-  if ((A.flags & KF_EMIT) && have_lm) {
+  if (emit && lm_valid) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p)
 #pragma unroll
@@ -206,8 +203,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + wave * A.row_dw;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
+  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
              A.row_dw);
   uint32_t lm[MAXP][MPASS];
@@ -238,13 +236,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
   const int env = A.env_ids ? uni(A.env_ids[i]) : A.dst_begin + i;
-  uint32_t* lds = smem + wave * A.row_dw;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   uint32_t* hdr = A.hdr + (size_t)env * HDR_DW;
   uint32_t* rows = A.rows + (size_t)env * A.row_dw;
   int32_t* army = A.army + (size_t)env * NSLOT * 64;
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
 
   B b;
+  b.larmy = nullptr;
   if (A.fresh) {
     b.W = A.s_width[i];
     b.H = A.s_height[i];
@@ -257,18 +256,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     b.N = b.W * b.H;
     b.recipW = (65536 + b.W - 1) / b.W;
     b.turn = 0;
-    b.episode = 0;
     b.hflags = A.fog ? HF_FOG : 0u;
     b.alive = (1u << b.P) - 1u;  // initializePlayers: Alive = true (engine_initializer.go:125-143)
-    b.winner = -1;
-    b.last_err = 0u;
-    b.cnt_steps = b.cnt_abort = b.cnt_done = 0u;
+    b.hv = (lane >= H_GIDX && lane < H_GIDX + 8) ? 0xFFFFFFFFu : 0u;  // GeneralIdx -1, counters / episode 0
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      b.own[p] = b.lst[p] = b.vis[p] = 0u;
-      b.army_count[p] = 0;
-      b.gidx[p] = -1;
-    }
+    for (int p = 0; p < MAXP; ++p) b.own[p] = b.lst[p] = b.vis[p] = 0u;
     b.chg = b.vch = b.gen = b.city = b.mtn = 0u;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) b.army[s] = 0;
@@ -349,13 +341,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     for (int p = 0; p < b.P; ++p) al |= (A.s_alive[po + p] ? 1u : 0u) << p;
     b.alive = al;
   }
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
-    if (A.s_army_count && p < b.P) b.army_count[p] = A.s_army_count[po + p];
-    if (A.s_general_idx && p < b.P) b.gidx[p] = A.s_general_idx[po + p];
+  for (int p = 0; p < b.P; ++p) {
+    if (A.s_army_count) b.hdr_set(H_ARMYCNT + p, (uint32_t)A.s_army_count[po + p]);
+    if (A.s_general_idx) b.hdr_set(H_GIDX + p, (uint32_t)A.s_general_idx[po + p]);
   }
   if (A.init) b.initial_setup();
-  b.store_hdr(hdr);
+  b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_army(army);
   b.store_rows(rows, lds, A.hs, true);
 }
@@ -371,8 +362,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
   const int env = A.env_begin + i;
-  uint32_t* lds = smem + wave * A.row_dw;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
+  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
              A.row_dw);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
@@ -430,9 +422,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
     if (lane == 0 && p < A.max_p) {
       const bool live = p < b.P;
       if (A.alive) A.alive[po + p] = (uint8_t)(live ? ((b.alive >> p) & 1u) : 0u);
-      if (A.army_count) A.army_count[po + p] = live ? b.army_count[p] : 0;
+      if (A.army_count) A.army_count[po + p] = live ? (int32_t)b.hdr_get(H_ARMYCNT + p) : 0;
       if (A.tile_count) A.tile_count[po + p] = live ? (int32_t)tcnt[p] : 0;
-      if (A.general_idx) A.general_idx[po + p] = live ? b.gidx[p] : -1;
+      if (A.general_idx) A.general_idx[po + p] = live ? (int32_t)b.hdr_get(H_GIDX + p) : -1;
     }
   }
 }
@@ -598,9 +590,11 @@ __global__ void selftest_kernel(int32_t* out) {
   if (wave_sum(v) != (uint32_t)(63 * 64 / 2 * 3 + 64)) fail = fail ? fail : 4;
   if (bperm(4 * ((lane * 7) & 63), v) != (uint32_t)(((lane * 7) & 63) * 3 + 1)) fail = fail ? fail : 5;
   if (spread4(0xA5u) != 0x10100101u) fail = fail ? fail : 6;
-  if (select_kth(0x80000105u, 0) != 0 || select_kth(0x80000105u, 1) != 2 || select_kth(0x80000105u, 2) != 8 ||
-      select_kth(0x80000105u, 3) != 31)
-    fail = fail ? fail : 7;
+  {  // select_kth is a wave-wide operation on uniform inputs
+    const bool bad = select_kth(0x80000105u, 0) != 0 || select_kth(0x80000105u, 1) != 2 || select_kth(0x80000105u, 2) != 8 ||
+                     select_kth(0x80000105u, 3) != 31;
+    fail = (!fail && bad) ? 7 : fail;
+  }
   const unsigned long long any = __builtin_amdgcn_ballot_w64(fail != 0);
   if (lane == 0) out[0] = any ? (int32_t)(__builtin_ctzll(any) * 16 + rdlane((uint32_t)fail, (int)__builtin_ctzll(any))) : 0;
 }
@@ -644,7 +638,7 @@ static inline size_t wave_lds(int row_dw) { return (size_t)WAVES_PER_BLOCK * (si
 hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((step_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       wave_lds(a.row_dw + decltype(S_)::value * 64), s, a);
     return hipGetLastError();
   });
 }
