@@ -111,26 +111,25 @@ def main():
     eng.build_board_pool(args.pool, args.seed * 7919 + rank)
     seed = args.seed
 
-    gather_buf = None
+    rg = None
     side = None
     if dist is not None and args.gather_envs > 0:
         # the one real exchange step of the path: compact experience/state slabs -> rank 0 (StreamAggregator side)
-        rec = eng.state_bytes_per_env()
+        from generalsreinforcementlearning_amd.sharding import RecordGather
         ge = min(args.gather_envs, B)
-        send = torch.empty(ge * rec, dtype=torch.uint8, device=dev)
-        gather_buf = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        rg = RecordGather(ge * eng.state_bytes_per_env(), dev, dst=0)
         side = torch.cuda.Stream()
 
     def one_step(k):
         eng.rollout(1, seed, 0, fused=False, want_stats=False)
-        if side is not None:
+        if rg is not None:
             ge = min(args.gather_envs, B)
             lo = (k * ge) % max(1, B - ge + 1)
-            eng.export_records(send.data_ptr(), lo, ge)  # on the compute stream, after this step's kernel
+            eng.export_records(rg.send.data_ptr(), lo, ge)  # on the compute stream, after this step's kernel
             side.wait_stream(stream)
             with torch.cuda.stream(side):
-                dist.gather(send, gather_buf, dst=0)
-            stream.wait_stream(side)  # send is reused next step
+                rg.gather()                                   # RCCL gather, overlapped with the next step
+            stream.wait_stream(side)                          # the send slab is reused next step
 
     def sync_all():
         torch.cuda.synchronize()

@@ -1,0 +1,211 @@
+// Package vecengine is the cgo shim a maintainer of
+// mitchelldurbincs/GeneralsReinforcementLearning adds to call the MI355X batched
+// turn engine (libgvec_hip.so, include/generals_vec.h) from Go.
+//
+// It keeps the reference's types at the boundary: actions are []core.Action
+// (core.MoveAction), errors are the core sentinels, masks are []bool in the
+// Engine.GetLegalActionMask order.  One VecEngine replaces B *game.Engine values
+// (internal/game/engine.go:17-43); like Engine it is not goroutine-safe and is
+// meant to be driven under the caller's lock (game_manager.go:576-602).
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.
+// Build with:  CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/generalsreinforcementlearning_amd -lgvec_hip" go build
+package vecengine
+
+/*
+#cgo CFLAGS:  -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../.. -lgvec_hip
+#include <stdlib.h>
+#include "generals_vec.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+
+	"github.com/mitchelldurbincs/GeneralsReinforcementLearning/internal/game/core"
+)
+
+// sentinel for each per-env code (core/errors.go:8-17; common.proto:39-48)
+var sentinels = map[int32]error{
+	1: core.ErrInvalidCoordinates, 2: core.ErrNotAdjacent, 3: core.ErrNotOwned, 4: core.ErrInsufficientArmy,
+	5: core.ErrGameOver, 6: core.ErrInvalidPlayer, 7: core.ErrMoveToSelf, 8: core.ErrTargetIsMountain,
+}
+
+// Config mirrors game.GameConfig (engine.go:45-58) for a batch.
+type Config struct {
+	NumEnvs, Width, Height, Players int
+	Device                          int
+	FogOfWar                        bool // GameState.FogOfWarEnabled (engine_initializer.go:118: true)
+	AutoReset                       bool
+}
+
+type VecEngine struct {
+	h         *C.gvec_handle
+	cfg       Config
+	stride    int
+	maskBytes int
+	actions   []C.gvec_action // [B][Players]
+	errs      []C.int32_t     // [B]
+	maskBits  []C.uint8_t     // [B][Players][maskBytes]
+}
+
+func apiErr(rc C.int32_t, what string) error {
+	if rc >= 0 {
+		return nil
+	}
+	return fmt.Errorf("%s: gvec status %d: %s", what, int(rc), C.GoString(C.gvec_last_error()))
+}
+
+// NewVecEngine replaces game.NewEngine (engine.go:62-71) for B engines.
+func NewVecEngine(cfg Config) (*VecEngine, error) {
+	var c C.gvec_config
+	C.gvec_config_default(&c)
+	c.num_envs, c.max_width, c.max_height, c.max_players = C.int32_t(cfg.NumEnvs), C.int32_t(cfg.Width), C.int32_t(cfg.Height), C.int32_t(cfg.Players)
+	c.device = C.int32_t(cfg.Device)
+	if !cfg.FogOfWar {
+		c.fog_of_war = 0
+	}
+	if cfg.AutoReset {
+		c.auto_reset = 1
+	}
+	e := &VecEngine{cfg: cfg}
+	if err := apiErr(C.gvec_create(&c, &e.h), "gvec_create"); err != nil {
+		return nil, err
+	}
+	e.stride = int(C.gvec_tile_stride(e.h))
+	e.maskBytes = int(C.gvec_mask_bytes(e.h))
+	e.actions = make([]C.gvec_action, cfg.NumEnvs*cfg.Players)
+	e.errs = make([]C.int32_t, cfg.NumEnvs)
+	e.maskBits = make([]C.uint8_t, cfg.NumEnvs*cfg.Players*e.maskBytes)
+	return e, nil
+}
+
+func (e *VecEngine) Close() { C.gvec_destroy(e.h); e.h = nil }
+
+// ResetBoards uploads one *core.Board per env (e.g. from mapgen.NewGenerator(...).GenerateMap(),
+// engine_initializer.go:106-110) and runs performInitialSetup (engine_initializer.go:218-225).
+func (e *VecEngine) ResetBoards(boards []*core.Board, players []int) error {
+	n := len(boards)
+	army := make([]C.int32_t, n*e.stride)
+	owner := make([]C.int8_t, n*e.stride)
+	typ := make([]C.uint8_t, n*e.stride)
+	w, h, p := make([]C.int32_t, n), make([]C.int32_t, n), make([]C.int32_t, n)
+	for i, b := range boards {
+		w[i], h[i], p[i] = C.int32_t(b.W), C.int32_t(b.H), C.int32_t(players[i])
+		for t, tile := range b.T { // row-major y*W+x, core/board.go:108
+			army[i*e.stride+t] = C.int32_t(tile.Army)
+			owner[i*e.stride+t] = C.int8_t(tile.Owner)
+			typ[i*e.stride+t] = C.uint8_t(tile.Type)
+		}
+	}
+	return apiErr(C.gvec_reset(e.h, nil, C.int32_t(n), &army[0], &owner[0], &typ[0], &w[0], &h[0], &p[0], C.GVEC_MEM_HOST), "gvec_reset")
+}
+
+func clamp8(v int) C.int8_t {
+	if v < -128 {
+		v = -128
+	}
+	if v > 127 {
+		v = 127
+	}
+	return C.int8_t(v)
+}
+
+// Step is Engine.Step (engine.go:75) for every env: actions[env] holds that env's []core.Action
+// for the turn (nil / missing player = no-op, converters.go:106-108).  The returned slice holds
+// nil or the wrapped sentinel per env, in the form Engine.Step returns it (core/errors.go:35-40).
+func (e *VecEngine) Step(actions [][]core.Action) ([]error, error) {
+	for i := range e.actions {
+		e.actions[i] = C.gvec_action{}
+	}
+	for env, list := range actions {
+		for _, a := range list {
+			m, ok := a.(*core.MoveAction)
+			if !ok || m == nil {
+				continue
+			}
+			if m.PlayerID < 0 || m.PlayerID >= e.cfg.Players {
+				continue // action_processor.go:56-60: ignored
+			}
+			ga := &e.actions[env*e.cfg.Players+m.PlayerID]
+			ga.from_x, ga.from_y, ga.to_x, ga.to_y = clamp8(m.FromX), clamp8(m.FromY), clamp8(m.ToX), clamp8(m.ToY)
+			ga.flags = C.GVEC_ACT_VALID
+			if !m.MoveAll {
+				ga.flags |= C.GVEC_ACT_HALF
+			}
+		}
+	}
+	rc := C.gvec_step(e.h, &e.actions[0], &e.errs[0], &e.maskBits[0], C.GVEC_MEM_HOST)
+	if err := apiErr(rc, "gvec_step"); err != nil {
+		return nil, err
+	}
+	out := make([]error, len(e.errs))
+	for i, code := range e.errs {
+		if code != 0 {
+			out[i] = core.WrapGameStateError(0, "action processing", sentinels[int32(code)])
+		}
+	}
+	return out, nil
+}
+
+// GetLegalActionMask is Engine.GetLegalActionMask(playerID) (engine.go:271-280) of one env,
+// unpacked from the bits the last Step returned.
+func (e *VecEngine) GetLegalActionMask(env, playerID, w, h int) []bool {
+	mask := make([]bool, w*h*4)
+	if playerID < 0 || playerID >= e.cfg.Players {
+		return mask // engine.go:273-276
+	}
+	bits := e.maskBits[(env*e.cfg.Players+playerID)*e.maskBytes:]
+	for i := range mask {
+		mask[i] = bits[i>>3]&(1<<uint(i&7)) != 0
+	}
+	return mask
+}
+
+// State is the part of game.GameState (state.go:25-34) + Engine flags callers read after a Step.
+type State struct {
+	Army                       []int32
+	Owner                      []int8
+	Type, Visible              []uint8
+	Changed, VisibilityChanged []uint8
+	Turn                       []int32
+	GameOver                   []uint8
+	Winner                     []int8
+	Alive                      []uint8
+	ArmyCount, GeneralIdx      []int32
+}
+
+// GameState reads envs [begin, begin+n): GameState() / IsGameOver() / GetWinner() /
+// GetChangedTiles() / GetVisibilityChangedTiles() (engine.go:197-298).
+func (e *VecEngine) GameState(begin, n int) (*State, error) {
+	s := &State{
+		Army: make([]int32, n*e.stride), Owner: make([]int8, n*e.stride), Type: make([]uint8, n*e.stride),
+		Visible: make([]uint8, n*e.stride), Changed: make([]uint8, n*e.stride), VisibilityChanged: make([]uint8, n*e.stride),
+		Turn: make([]int32, n), GameOver: make([]uint8, n), Winner: make([]int8, n),
+		Alive: make([]uint8, n*e.cfg.Players), ArmyCount: make([]int32, n*e.cfg.Players), GeneralIdx: make([]int32, n*e.cfg.Players),
+	}
+	var v C.gvec_state_view
+	v.army = (*C.int32_t)(unsafe.Pointer(&s.Army[0]))
+	v.owner = (*C.int8_t)(unsafe.Pointer(&s.Owner[0]))
+	v._type = (*C.uint8_t)(unsafe.Pointer(&s.Type[0]))
+	v.visible = (*C.uint8_t)(unsafe.Pointer(&s.Visible[0]))
+	v.changed = (*C.uint8_t)(unsafe.Pointer(&s.Changed[0]))
+	v.vis_changed = (*C.uint8_t)(unsafe.Pointer(&s.VisibilityChanged[0]))
+	v.turn = (*C.int32_t)(unsafe.Pointer(&s.Turn[0]))
+	v.done = (*C.uint8_t)(unsafe.Pointer(&s.GameOver[0]))
+	v.winner = (*C.int8_t)(unsafe.Pointer(&s.Winner[0]))
+	v.alive = (*C.uint8_t)(unsafe.Pointer(&s.Alive[0]))
+	v.army_count = (*C.int32_t)(unsafe.Pointer(&s.ArmyCount[0]))
+	v.general_idx = (*C.int32_t)(unsafe.Pointer(&s.GeneralIdx[0]))
+	return s, apiErr(C.gvec_read_state(e.h, C.int32_t(begin), C.int32_t(n), &v, C.GVEC_MEM_HOST), "gvec_read_state")
+}
+
+// ComputePlayerVisibility is Engine.ComputePlayerVisibility(playerID) (visibility.go:153) for all envs.
+func (e *VecEngine) ComputePlayerVisibility(playerID int) (visible, fog []uint8, err error) {
+	visible = make([]uint8, e.cfg.NumEnvs*e.stride)
+	fog = make([]uint8, e.cfg.NumEnvs*e.stride)
+	rc := C.gvec_player_visibility(e.h, C.int32_t(playerID), (*C.uint8_t)(unsafe.Pointer(&visible[0])), (*C.uint8_t)(unsafe.Pointer(&fog[0])), C.GVEC_MEM_HOST)
+	return visible, fog, apiErr(rc, "gvec_player_visibility")
+}

@@ -54,3 +54,11 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "generals_oracle" not in txt and "_oracle" not in txt, f
+
+
+def test_cpp_host_mirror_compiles():
+    import subprocess, tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
+        f.write('#include "generalsreinforcementlearning_amd/host/vec_engine.hpp"\nint main() { gvec::GameConfig c; (void)c; return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I", ROOT, f.name])
+    os.unlink(f.name)
