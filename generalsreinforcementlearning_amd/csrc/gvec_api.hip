@@ -33,7 +33,7 @@ static void set_err(const char* fmt, ...) {
 struct gvec_handle {
   gvec_config cfg;
   Variant var;
-  int stride, hs, row_dw, mask_dw, mask_bytes, army_dw, maxp;
+  int stride, fd, row_dw, mask_dw, mask_bytes, army_dw, maxp;
   hipStream_t stream;
   uint32_t* d_hdr = nullptr;
   uint32_t* d_rows = nullptr;
@@ -78,7 +78,7 @@ StepArgs base_args(const gvec_handle* h) {
   a.pool_rows = h->p_rows;
   a.pool_army = h->p_army;
   a.num_envs = h->cfg.num_envs;
-  a.hs = h->hs;
+  a.fd = h->fd;
   a.row_dw = h->row_dw;
   a.mask_dw = h->mask_dw;
   a.pool_size = h->pool_size;
@@ -185,7 +185,7 @@ int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* ar
   a.max_p = h->maxp;
   a.max_w = h->cfg.max_width;
   a.max_h = h->cfg.max_height;
-  a.hs = h->hs;
+  a.fd = h->fd;
   a.row_dw = h->row_dw;
   a.fresh = fresh ? 1u : 0u;
   a.init = init ? 1u : 0u;
@@ -255,8 +255,8 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
     set_err("no kernel variant for %d players / %d tiles", cfg->max_players, h->stride);
     return GVEC_E_INVALID;
   }
-  h->hs = (int)round_up((size_t)cfg->max_height, 4);
-  h->row_dw = (3 * h->var.maxp + 5) * h->hs;
+  h->fd = (h->stride + 31) / 32;  // dwords per flat bit-plane
+  h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 5) * h->fd, 4);
   h->army_dw = h->var.nslot * 64;
   h->mask_bytes = (int)round_up((size_t)(h->stride + 1) / 2, 16);
   h->mask_dw = h->mask_bytes / 4;
@@ -486,7 +486,7 @@ static int32_t export_range(gvec_handle* h, int32_t env_begin, int32_t n, const 
   a.n = n;
   a.stride = h->stride;
   a.max_p = h->maxp;
-  a.hs = h->hs;
+  a.fd = h->fd;
   a.row_dw = h->row_dw;
   a.vis_player = vis_player;
   RET_IF(stage_out(b[0], v->army, nt, mem, &a.army_out));

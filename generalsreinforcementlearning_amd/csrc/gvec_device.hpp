@@ -3,19 +3,23 @@
 // One 64-lane wavefront owns one board ("env").  The board lives in registers in two
 // layouts at once (DESIGN.md "Data layout"):
 //
-//   * ROW domain  — lane y holds row y of every bit-plane as one u32 (W <= 32 bits):
-//       own[p]  tile.Owner == p            (core/board.go:8)
-//       lst[p]  tile in Players[p].OwnedTiles (game/state.go:12; SURVEY H6 "plane L")
-//       vis[p]  bit p of tile.VisibleBitfield (core/board.go:11)
+//   * FLAT domain — every bit-plane is the row-major bit string of the board (bit t = tile
+//     t = y*W + x, the reference's index, core/board.go:108); lane i holds bits 32i..32i+31:
+//       own[p]  tile.Owner == p                  (core/board.go:8)
+//       lst[p]  tile in Players[p].OwnedTiles    (game/state.go:12; SURVEY H6 "plane L")
+//       vis[p]  bit p of tile.VisibleBitfield    (core/board.go:11)
 //       chg     GameState.ChangedTiles, vch GameState.VisibilityChangedTiles (state.go:29,33)
-//       gen/city/mtn  tile.Type one-hot     (core/board.go:20-26)
-//     3x3 / 5x5 stencils, ownership algebra and the legal-move predicate are a handful
-//     of shifts, DPP wave shifts and ANDs here.
+//       gen/city/mtn  tile.Type one-hot          (core/board.go:20-26)
+//     Neighbours are funnel shifts of the string by 1 (x +- 1, with column guards) and by W
+//     (y +- 1): a DPP wave shift + v_alignbit each.  Ownership algebra and the legal-move
+//     predicate are plain ANDs.  13 lanes carry a 20x20 board, 32 lanes a 32x32 one.
 //   * TILE domain — lane l, slot s holds Tile.Army of tile t = 64*s + l (int32, H12).
+//     A flat plane reaches the tile domain with one ds_bpermute (dword 2s + (l>>5)) and a
+//     bit-field extract at bit l&31: no per-tile coordinates are ever computed.
 //
-// Row planes are staged HBM -> LDS -> registers with flat 16-byte coalesced accesses;
-// armies are loaded straight into registers, 256 B per wave instruction.
-// Everything is integer / bit work: no MFMA anywhere (HBM-roofline kernel).
+// Planes are staged HBM -> LDS -> registers with flat 16-byte coalesced accesses; armies are
+// loaded straight into registers, 256 B per wave instruction.  Integer / bit work only: no MFMA
+// anywhere (HBM-roofline kernel).
 //
 // Every routine cites the Go function it reproduces (paths relative to
 // /root/reference/internal/game/).  Semantics are the plane re-statement derived in
@@ -29,7 +33,7 @@
 namespace gvec {
 
 // ---- resident record layout (per env) -------------------------------------------------
-// hdr  : HDR_DW u32          rows : M*HS u32, plane-major [m][y]     army : NSLOT*64 i32
+// hdr  : HDR_DW u32      planes : M*FD u32 (+pad to 4), plane-major [m][i]     army : NSLOT*64 i32
 constexpr int HDR_DW = 24;
 enum : int {
   H_TURN = 0,     // GameState.Turn
@@ -38,14 +42,14 @@ enum : int {
   H_EPISODE = 3,  // re-deal counter (auto-reset)
   H_ARMYCNT = 4,  // [8] Player.ArmyCount
   H_GIDX = 12,    // [8] Player.GeneralIdx
-  H_RECIPW = 20,  // ceil(65536 / W): exact t / W for t < 1024 (see tile_coords)
-  H_CNT_STEPS = 21,   // lifetime counters of this env slot (rollout statistics)
+  H_RECIPW = 20,  // ceil(65536 / W): exact t / W for t < 1024
+  H_CNT_STEPS = 21,  // lifetime counters of this env slot (rollout statistics)
   H_CNT_ABORT = 22,
   H_CNT_DONE = 23
 };
 constexpr uint32_t HF_DONE = 1u, HF_FOG = 2u;
 
-// plane order inside the rows block; the last three never change after reset
+// plane order inside the planes block; the last three never change after reset
 template <int MAXP>
 struct Planes {
   static constexpr int OWN = 0, LST = MAXP, VIS = 2 * MAXP, CHG = 3 * MAXP, VCH = 3 * MAXP + 1, GEN = 3 * MAXP + 2,
@@ -59,16 +63,16 @@ constexpr uint32_t KF_LMVALID = 16u;   // args.legal already holds the masks of 
 
 struct StepArgs {
   uint32_t* hdr;
-  uint32_t* rows;
+  uint32_t* rows;  // the planes block
   int32_t* army;
-  const gvec_action* actions;  // [B][MAXP] (ignored with KF_AGENT)
+  const gvec_action* actions;  // [B][pstride] (ignored with KF_AGENT)
   gvec_action* actions_out;    // optional: where the agent records what it played
   int32_t* err;                // [B] or null
-  uint32_t* legal;             // [B][MAXP][mask_dw]
+  uint32_t* legal;             // [B][pstride][mask_dw]
   const uint32_t* pool_hdr;
   const uint32_t* pool_rows;
   const int32_t* pool_army;
-  int32_t num_envs, hs, row_dw, mask_dw, pool_size;
+  int32_t num_envs, fd, row_dw, mask_dw, pool_size;  // fd = dwords per plane = ceil(max tiles / 32)
   int32_t pstride;  // players per env in actions / legal buffers (gvec_config.max_players)
   int32_t prod_general, prod_city, prod_normal, interval;
   int32_t turns, invalid_permille;
@@ -76,16 +80,18 @@ struct StepArgs {
 };
 
 // ---- wave primitives --------------------------------------------------------------------
+// NOTE: ds_bpermute / DPP read 0 from lanes that are masked off in EXEC.  Every cross-lane
+// helper below must therefore be called under wave-uniform control flow only.
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 template <int CTRL, int RM = 0xf, int BM = 0xf>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, BM, false);
 }
-// lane y receives lane y-1 (row above); lane 0 receives 0     [DPP wave_shr:1]
-__device__ __forceinline__ uint32_t from_above(uint32_t v) { return dpp0<0x138>(v); }
-// lane y receives lane y+1 (row below); lane 63 receives 0    [DPP wave_shl:1]
-__device__ __forceinline__ uint32_t from_below(uint32_t v) { return dpp0<0x130>(v); }
+// lane i receives lane i-1 (the 32 tiles before); lane 0 receives 0     [DPP wave_shr:1]
+__device__ __forceinline__ uint32_t from_prev(uint32_t v) { return dpp0<0x138>(v); }
+// lane i receives lane i+1 (the 32 tiles after); lane 63 receives 0     [DPP wave_shl:1]
+__device__ __forceinline__ uint32_t from_next(uint32_t v) { return dpp0<0x130>(v); }
 
 // inclusive prefix sum over the 64 lanes (row_shr 1/2/4/8, then row_bcast 15/31)
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
@@ -101,11 +107,8 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return rdlane(wave_scan_add(v), 63); }
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
-// NOTE: ds_bpermute / DPP read 0 from lanes that are masked off in EXEC.  Every cross-lane
-// helper below must therefore be called under wave-uniform control flow only.
 __device__ __forceinline__ uint32_t bperm(int byte_addr, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
 }
@@ -144,15 +147,13 @@ struct Board {
   using PL = Planes<MAXP>;
   static constexpr int MPASS = (NSLOT > 8) ? 2 : 1;  // legal-mask dwords per lane (8 tiles each)
 
-  // row domain
+  // flat domain
   uint32_t own[MAXP], lst[MAXP], vis[MAXP], chg, vch, gen, city, mtn;
-  uint32_t rowmask;  // in-board bits of this lane's row (0 for y >= H)
+  uint32_t valid;  // bits t < N
+  uint32_t ncol0;  // bits with x != 0      (guards a shift towards higher t)
+  uint32_t ncolL;  // bits with x != W - 1  (guards a shift towards lower t)
   // tile domain
   int32_t army[NSLOT];
-  int ysel[NSLOT];  // 4 * min(y, 63) of tile 64*s + lane   (byte address for ds_bpermute)
-  int xsh[NSLOT];   // x of that tile
-  // flat-byte domain: lane j (+64*pass) assembles bits [8j, 8j+8) of a plane's row-major bit string
-  int fb_ysel[MPASS], fb_x0[MPASS];
   // header: lane k holds header dword k (Player.ArmyCount / GeneralIdx, counters, ... live here;
   // only what the turn logic branches on is also kept wave-uniform below)
   uint32_t hv;
@@ -161,25 +162,33 @@ struct Board {
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
 
-  // ---------------------------------------------------------------------------------------
-  __device__ __forceinline__ void tile_coords() {
-    const int lane = lane_id();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-      int t = 64 * s + lane;
-      int y = (t * recipW) >> 16;  // == t / W for t < 1024, W <= 32 (error term < 1/64 < 1/W)
-      xsh[s] = t - y * W;
-      ysel[s] = 4 * (y < 63 ? y : 63);  // lane 63 never holds a board row (H <= 32)
-    }
-#pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      int f = 8 * (lane + 64 * k);
-      int y = (f * recipW) >> 16;
-      fb_x0[k] = f - y * W;
-      fb_ysel[k] = 4 * (y < 62 ? y : 62);  // y and y+1 must both be empty rows when clamped
-    }
-    rowmask = (lane < H) ? (0xFFFFFFFFu >> (32 - W)) : 0u;
+  // ---- geometry masks of this board size ----------------------------------------------------
+  __device__ __forceinline__ void geometry() {
+    const int t0 = 32 * (lane_id() & 31);
+    const int left = N - t0;
+    valid = (lane_id() >= 32 || left <= 0) ? 0u : (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
+    uint32_t pat = 0u;  // bits at multiples of W below 32 (wave-uniform, <= 32/W + 1 iterations)
+    for (int k = 0; k < 32; k += W) pat |= 1u << k;
+    const int q = (t0 * recipW) >> 16;  // t0 / W, exact for t0 < 1024
+    const int x0 = t0 - q * W;          // column of this lane's first tile
+    const uint32_t col0 = pat << (x0 ? W - x0 : 0);
+    ncol0 = ~col0;
+    ncolL = ~__builtin_amdgcn_alignbit(from_next(col0), col0, 1);  // t is in the last column iff t+1 is in column 0
   }
+
+  // ---- flat-string shifts: bit t of the result = bit (t -+ k) of m ---------------------------
+  __device__ __forceinline__ uint32_t up1(uint32_t m) const { return __builtin_amdgcn_alignbit(m, from_prev(m), 31); }  // from t-1
+  __device__ __forceinline__ uint32_t dn1(uint32_t m) const { return __builtin_amdgcn_alignbit(from_next(m), m, 1); }   // from t+1
+  __device__ __forceinline__ uint32_t upW(uint32_t m) const {                                                           // from t-W
+    return __builtin_amdgcn_alignbit(m, from_prev(m), (uint32_t)(32 - W) & 31u);
+  }
+  __device__ __forceinline__ uint32_t dnW(uint32_t m) const {  // from t+W
+    return (uint32_t)((((uint64_t)from_next(m) << 32) | (uint64_t)m) >> W);
+  }
+  __device__ __forceinline__ uint32_t dil_h(uint32_t m) const { return m | (up1(m) & ncol0) | (dn1(m) & ncolL); }
+  __device__ __forceinline__ uint32_t dil_v(uint32_t m) const { return (m | upW(m) | dnW(m)) & valid; }
+  // 3x3 / 5x5 neighbourhoods (visibility_optimized.go:9-13, :104-105)
+  __device__ __forceinline__ uint32_t dil3(uint32_t m) const { return dil_v(dil_h(m)); }
 
   // ---- load / store ---------------------------------------------------------------------
   __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
@@ -207,24 +216,24 @@ struct Board {
     if (lane < HDR_DW) hdr_env[lane] = hv;
   }
 
-  // rows: HBM --(flat dwordx4)--> LDS --(ds_read_b32, lane = row)--> registers
-  __device__ __forceinline__ void load_rows(const uint32_t* rows_env, uint32_t* lds, int hs, int row_dw) {
+  // planes: HBM --(flat dwordx4)--> LDS --(ds_read_b32, lane = dword of the bit string)--> registers
+  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, uint32_t* lds, int fd, int row_dw) {
     const int lane = lane_id();
     for (int c = lane; c * 4 < row_dw; c += 64) {
       uint4 q = *reinterpret_cast<const uint4*>(rows_env + 4 * c);
       *reinterpret_cast<uint4*>(lds + 4 * c) = q;
     }
     wave_lds_fence();
-    const bool on = lane < hs;
+    const bool on = lane < fd;
     const uint32_t* l = lds + (on ? lane : 0);
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      uint32_t a = l[(PL::OWN + p) * hs], b = l[(PL::LST + p) * hs], c = l[(PL::VIS + p) * hs];
+      uint32_t a = l[(PL::OWN + p) * fd], b = l[(PL::LST + p) * fd], c = l[(PL::VIS + p) * fd];
       own[p] = on ? a : 0u;
       lst[p] = on ? b : 0u;
       vis[p] = on ? c : 0u;
     }
-    uint32_t a = l[PL::CHG * hs], b = l[PL::VCH * hs], c = l[PL::GEN * hs], d = l[PL::CITY * hs], e = l[PL::MTN * hs];
+    uint32_t a = l[PL::CHG * fd], b = l[PL::VCH * fd], c = l[PL::GEN * fd], d = l[PL::CITY * fd], e = l[PL::MTN * fd];
     chg = on ? a : 0u;
     vch = on ? b : 0u;
     gen = on ? c : 0u;
@@ -233,29 +242,29 @@ struct Board {
     wave_lds_fence();
   }
 
-  __device__ __forceinline__ void store_rows(uint32_t* rows_env, uint32_t* lds, int hs, bool with_types) const {
+  __device__ __forceinline__ void store_planes(uint32_t* rows_env, uint32_t* lds, int fd, bool with_types) const {
     const int lane = lane_id();
-    if (lane < hs) {
+    if (lane < fd) {
       uint32_t* l = lds + lane;
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
-        l[(PL::OWN + p) * hs] = own[p];
-        l[(PL::LST + p) * hs] = lst[p];
-        l[(PL::VIS + p) * hs] = vis[p];
+        l[(PL::OWN + p) * fd] = own[p];
+        l[(PL::LST + p) * fd] = lst[p];
+        l[(PL::VIS + p) * fd] = vis[p];
       }
-      l[PL::CHG * hs] = chg;
-      l[PL::VCH * hs] = vch;
+      l[PL::CHG * fd] = chg;
+      l[PL::VCH * fd] = vch;
       if (with_types) {
-        l[PL::GEN * hs] = gen;
-        l[PL::CITY * hs] = city;
-        l[PL::MTN * hs] = mtn;
+        l[PL::GEN * fd] = gen;
+        l[PL::CITY * fd] = city;
+        l[PL::MTN * fd] = mtn;
       }
     }
     wave_lds_fence();
-    const int ndw = (with_types ? PL::COUNT : PL::MUTABLE) * hs;
+    const int ndw = (with_types ? PL::COUNT : PL::MUTABLE) * fd;
     for (int c = lane; c * 4 < ndw; c += 64) {
-      // the tail chunk may cover the first dwords of the (unchanged) type planes: those
-      // were staged into LDS by load_rows, so the bytes written back are identical.
+      // the tail chunk may cover the first dwords of the (unchanged) type planes or the block's
+      // padding: those were staged into LDS by load_planes, so identical bytes are written back.
       uint4 q = *reinterpret_cast<const uint4*>(lds + 4 * c);
       *reinterpret_cast<uint4*>(rows_env + 4 * c) = q;
     }
@@ -293,42 +302,23 @@ struct Board {
   __device__ __forceinline__ void army_set(int t, int val) {
     if (lane_id() == 0) larmy[t] = val;
   }
-  __device__ __forceinline__ bool bit_at(uint32_t plane, int x, int y) const { return (rdlane(plane, y) >> x) & 1u; }
+  __device__ __forceinline__ bool bit_at(uint32_t plane, int t) const { return (rdlane(plane, t >> 5) >> (t & 31)) & 1u; }
+  // the single bit of tile t as a flat plane
+  __device__ __forceinline__ uint32_t tile_bit(int t) const { return (lane_id() == (t >> 5)) ? (1u << (t & 31)) : 0u; }
 
-  // tile-domain 0/1 predicate of a row-domain plane
-  __device__ __forceinline__ uint32_t gather(uint32_t plane, int s) const { return (bperm(ysel[s], plane) >> xsh[s]) & 1u; }
-  // tile-domain all-ones / zero mask of a row-domain plane
+  // tile-domain all-ones / zero mask (gather_mask) or 0/1 (gather) of a flat plane: tile 64s+l is
+  // bit l&31 of dword 2s + (l>>5)
   __device__ __forceinline__ int32_t gather_mask(uint32_t plane, int s) const {
-    return -(int32_t)((bperm(ysel[s], plane) >> xsh[s]) & 1u);
+    const int lane = lane_id();
+    return __builtin_amdgcn_sbfe((int32_t)bperm(((lane >> 5) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
+  __device__ __forceinline__ uint32_t gather(uint32_t plane, int s) const { return (uint32_t)gather_mask(plane, s) & 1u; }
 
-  // bits [8j, 8j+8) of the plane's row-major bit string (j = lane + 64*pass)
-  __device__ __forceinline__ uint32_t flat_byte(uint32_t plane, int pass) const {
-    if (W >= 8) {  // 8 consecutive tiles touch at most two rows
-      const uint32_t r0 = bperm(fb_ysel[pass], plane), r1 = bperm(fb_ysel[pass] + 4, plane);
-      const uint64_t two = (uint64_t)r0 | ((uint64_t)r1 << W);
-      return (uint32_t)(two >> fb_x0[pass]) & 0xFFu;
-    }
-    // narrow boards (W < 8, reference tests): up to 9 rows contribute; wave-uniform trip count
-    uint64_t acc = 0ull;
-    const int nr = (8 + W - 1) / W + 1;
-    for (int r = 0; r < nr; ++r) {
-      int a = fb_ysel[pass] + 4 * r;
-      a = a < 252 ? a : 252;  // lane 63 holds no board row
-      acc |= (uint64_t)bperm(a, plane) << (r * W);
-    }
-    return (uint32_t)(acc >> fb_x0[pass]) & 0xFFu;
-  }
-
-  // ---- 3x3 / 5x5 dilations (visibility_optimized.go:9-13, :104-105) -----------------------
-  __device__ __forceinline__ uint32_t dil3(uint32_t m) const {
-    uint32_t h = m | (m << 1) | (m >> 1);
-    return (h | from_above(h) | from_below(h)) & rowmask;
-  }
-  __device__ __forceinline__ uint32_t dil5(uint32_t m) const {
-    uint32_t h = m | (m << 1) | (m >> 1) | (m << 2) | (m >> 2);
-    uint32_t a = from_above(h), b = from_below(h);
-    return (h | a | b | from_above(a) | from_below(b)) & rowmask;
+  // tile-domain predicates -> flat plane (the ballot of slot s is dwords 2s, 2s+1 of the bit string)
+  __device__ __forceinline__ void scatter(uint32_t& plane, unsigned long long ballot, int s) const {
+    const int lane = lane_id();
+    plane = (lane == 2 * s) ? (uint32_t)ballot : plane;
+    plane = (lane == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
   }
 
   // ---- Engine.updateFogOfWarOptimized (visibility_optimized.go:16-97) --------------------
@@ -337,18 +327,21 @@ struct Board {
     const int nv = (int)wave_sum(__builtin_popcount(vch));
     if (turn == 0 || nv > N / 10) {  // :22-26 full: clear, then 3x3 around every listed tile of alive players (:33-53)
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) vis[p] = ((alive >> p) & 1u) ? dil3(lst[p]) : 0u;
+      for (int p = 0; p < MAXP; ++p) {
+        const uint32_t d = dil3(lst[p]);  // cross-lane: outside the (uniform) select
+        vis[p] = ((alive >> p) & 1u) ? d : 0u;
+      }
       return;
     }
     if (nv == 0) return;  // incremental update over an empty set is the identity
     // :56-97 affected = board owners within 5x5 of V (:100-116); clear all players in 3x3 of V
     // (:132-150); re-light affected, alive players from their lists (:85-94)
-    const uint32_t near5 = dil5(vch), clr = ~dil3(vch);
+    const uint32_t near3 = dil3(vch), near5 = dil3(near3), clr = ~near3;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      const bool affected = wave_any((own[p] & near5) != 0u);
+      const bool relight = wave_any((own[p] & near5) != 0u) && ((alive >> p) & 1u);
       uint32_t v = vis[p] & clr;
-      if (affected && ((alive >> p) & 1u)) v |= dil3(lst[p]);
+      if (relight) v |= dil3(lst[p]);  // wave-uniform branch
       vis[p] = v;
     }
   }
@@ -375,12 +368,11 @@ struct Board {
       // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two
       // or more generals that order depends on Go map iteration.  Here: the highest tile index.
       const uint32_t g = lst[p] & gen;
-      const unsigned long long rowsg = __builtin_amdgcn_ballot_w64(g != 0u);
+      const unsigned long long dw = __builtin_amdgcn_ballot_w64(g != 0u);
       int gi = -1;
-      if (rowsg) {
-        const int y = 63 - __builtin_clzll(rowsg);
-        const uint32_t r = rdlane(g, y);
-        gi = y * W + (31 - __builtin_clz(r));
+      if (dw) {
+        const int i = 63 - __builtin_clzll(dw);
+        gi = 32 * i + (31 - __builtin_clz(rdlane(g, i)));
       }
       hdr_set(H_GIDX + p, (uint32_t)gi);
       alive |= (gi >= 0) ? (1u << p) : 0u;  // :52-54 / :133-135
@@ -393,7 +385,7 @@ struct Board {
     uint32_t listed_alive = 0u;                // :39-45: lists of alive players, owner NOT re-checked (H7)
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) listed_alive |= ((alive >> p) & 1u) ? lst[p] : 0u;
-    const uint32_t normal = ~(gen | city | mtn) & rowmask;
+    const uint32_t normal = ~(gen | city | mtn) & valid;
     const uint32_t mg = (pg > 0) ? (listed_alive & gen) : 0u;
     const uint32_t mc = (pc > 0) ? (listed_alive & city) : 0u;
     const uint32_t mn = (grow && pn > 0) ? (listed_alive & normal) : 0u;
@@ -424,7 +416,6 @@ struct Board {
   // same-tile and adjacency checks of MoveAction.Validate (core/action.go:58-76), tile indices.
   struct ActVec {
     uint32_t meta;  // bits 0-3 static Validate code, bit 4 present (non-nil), bit 5 half
-    uint32_t xy;    // fx | fy<<8 | tx<<16 | ty<<24 (as submitted)
     int ft, tt;     // y*W + x of source / target
   };
   __device__ __forceinline__ ActVec prevalidate(uint32_t alo, uint32_t ahi) const {
@@ -435,11 +426,10 @@ struct Board {
     const int dx = fx - tx, dy = fy - ty;
     const int md = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
     uint32_t code = 0u;
-    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;        // action.go:72-76 (orthogonal, one step)
-    code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;        // :67-69
-    code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;    // :58-64
+    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;      // action.go:72-76 (orthogonal, one step)
+    code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;      // :67-69
+    code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;  // :58-64
     v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
-    v.xy = alo;
     v.ft = fy * W + fx;
     v.tt = ty * W + tx;
     return v;
@@ -455,20 +445,15 @@ struct Board {
     if (!(m & 16u)) return;              // nil action
     if (!((alive >> PID) & 1u)) return;  // action_processor.go:56-60 (Alive as last written, H2)
     uint32_t code = m & 15u;
-    int fa = 0, ta = 0, fx = 0, fy = 0, tx = 0, ty = 0, ft = 0, tt = 0;
+    int fa = 0, ta = 0, ft = 0, tt = 0;
     if (!code) {
-      const uint32_t a = rdlane(av.xy, PID);
-      fx = (int)(a & 0xFFu);
-      fy = (int)((a >> 8) & 0xFFu);
-      tx = (int)((a >> 16) & 0xFFu);
-      ty = (int)(a >> 24);
       ft = (int)rdlane((uint32_t)av.ft, PID);
       tt = (int)rdlane((uint32_t)av.tt, PID);
       fa = army_get(ft);
       ta = army_get(tt);
-      if (!bit_at(own[PID], fx, fy)) code = GVEC_ERR_NOT_OWNED;           // action.go:82-84
-      else if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;                // :87-89
-      else if (bit_at(mtn, tx, ty)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;   // :96-98
+      if (!bit_at(own[PID], ft)) code = GVEC_ERR_NOT_OWNED;          // action.go:82-84
+      else if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;           // :87-89
+      else if (bit_at(mtn, tt)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;  // :96-98
     }
     if (code) {  // action_processor.go:66-77: remember the FIRST error, keep going
       first_err = first_err ? first_err : code;
@@ -476,24 +461,23 @@ struct Board {
     }
     int n = (m & 32u) ? (fa / 2) : (fa - 1);  // movement.go:40-49
     n = (n == 0) ? 1 : n;
-    const int lane = lane_id();
-    const uint32_t fbit = (lane == fy) ? (1u << fx) : 0u, tbit = (lane == ty) ? (1u << tx) : 0u;
+    const uint32_t fbit = tile_bit(ft), tbit = tile_bit(tt);
     army_set(ft, fa - n);  // :54
     chg |= fbit | tbit;    // :57-60
-    if (bit_at(own[PID], tx, ty)) {  // :62-66 own tile: consolidate
+    if (bit_at(own[PID], tt)) {  // :62-66 own tile: consolidate
       army_set(tt, ta + n);
     } else if (n > ta) {  // :69-82 capture (ties favour the defender)
       int prev = -1;
 #pragma unroll
       for (int q = 0; q < MAXP; ++q) {
-        if (bit_at(own[q], tx, ty)) prev = q;
+        if (bit_at(own[q], tt)) prev = q;
         own[q] &= ~tbit;
       }
       own[PID] |= tbit;
       army_set(tt, n - ta);
       vch |= tbit;  // action_processor.go:84-86
       // movement.go:105-108
-      if (bit_at(gen, tx, ty) && prev >= 0 && !((elim_seen >> prev) & 1u)) {
+      if (bit_at(gen, tt) && prev >= 0 && !((elim_seen >> prev) & 1u)) {
         orders |= (uint64_t)((uint32_t)prev | ((uint32_t)PID << 4)) << (8 * n_orders);
         n_orders++;
         elim_seen |= 1u << prev;
@@ -580,30 +564,27 @@ struct Board {
 
   // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73) --------------------
   // out[p][k]: lane j holds bits [32*(j+64k), +32) of player p's mask, bit i = action
-  // (y*W+x)*4+d with d = 0 up, 1 right, 2 down, 3 left (H10).
+  // (y*W+x)*4+d with d = 0 up, 1 right, 2 down, 3 left (H10).  Output dword j covers tiles
+  // 8j..8j+7 = byte j&3 of flat dword j>>2: one bpermute per plane, then a x4 bit spread.
+  __device__ __forceinline__ uint32_t flat_byte(uint32_t plane, int pass) const {
+    const int j = lane_id() + 64 * pass;
+    return __builtin_amdgcn_ubfe(bperm((j >> 2) << 2, plane), (uint32_t)(8 * (j & 3)), 8u);
+  }
   __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS]) const {
-    const int lane = lane_id();
-    // army > 1 as a flat bit string: dword i in lane i
-    uint32_t gt1_dw = 0u;
+    uint32_t gt1 = 0u;  // army > 1 as a flat plane
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(army[s] > 1);
-      gt1_dw = (lane == 2 * s) ? (uint32_t)b : gt1_dw;
-      gt1_dw = (lane == 2 * s + 1) ? (uint32_t)(b >> 32) : gt1_dw;
-    }
-    const uint32_t notm = ~mtn & rowmask;  // in-board, not a mountain (Validate :58-64,:96-98)
-    const uint32_t ok_up = from_above(notm) & rowmask, ok_dn = from_below(notm) & rowmask;
-    const uint32_t ok_rt = notm >> 1, ok_lf = (notm << 1) & rowmask;
+    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
+    const uint32_t notm = ~mtn & valid;  // in-board, not a mountain (Validate :58-64,:96-98)
+    const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);                  // target y-1 / y+1
+    const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;  // target x+1 / x-1
 #pragma unroll
     for (int k = 0; k < MPASS; ++k) {
-      const int j = lane + 64 * k;
       const uint32_t okn = spread4(flat_byte(ok_up, k)) | (spread4(flat_byte(ok_rt, k)) << 1) |
                            (spread4(flat_byte(ok_dn, k)) << 2) | (spread4(flat_byte(ok_lf, k)) << 3);
-      const uint32_t gt1 = (bperm((j >> 2) * 4, gt1_dw) >> (8 * (j & 3))) & 0xFFu;
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
         // :26-28 alive, :37 listed, :41 owner == pid && army > 1
-        const uint32_t cb = flat_byte(lst[p] & own[p], k) & gt1;  // cross-lane: keep it unconditional
+        const uint32_t cb = flat_byte(lst[p] & own[p] & gt1, k);  // cross-lane: keep it unconditional
         const uint32_t can = ((alive >> p) & 1u) ? cb : 0u;
         out[p][k] = (spread4(can) * 15u) & okn;
       }

@@ -83,14 +83,14 @@ __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
 // =========================================================================================
 template <int MAXP, int NSLOT>
 __device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t* hdr, const uint32_t* rows,
-                                           const int32_t* army, uint32_t* lds, int hs, int row_dw) {
+                                           const int32_t* army, uint32_t* lds, int fd, int row_dw) {
   b.load_hdr(hdr);
-  b.tile_coords();
+  b.geometry();
   b.load_army(army);
-  b.load_rows(rows, lds, hs, row_dw);
+  b.load_planes(rows, lds, fd, row_dw);
 }
 
-// per-wave LDS: [row_dw] staging of the bit-rows, then [NSLOT*64] army shadow
+// per-wave LDS: [row_dw] staging of the bit-planes, then [NSLOT*64] army shadow
 template <int NSLOT>
 __device__ __forceinline__ uint32_t* wave_lds(uint32_t* smem, int wave, int row_dw, int32_t** larmy) {
   uint32_t* base = smem + (size_t)wave * (size_t)(row_dw + NSLOT * 64);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   B b;
   uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
   const size_t army_dw = (size_t)NSLOT * 64;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.hs,
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.fd,
              A.row_dw);
 
   uint32_t lm[MAXP][MPASS];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
         const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
         const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
         load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * army_dw, lds,
-                   A.hs, A.row_dw);
+                   A.fd, A.row_dw);
         b.hdr_set(H_EPISODE, episode);
         b.hdr_set(H_CNT_STEPS, cs);
         b.hdr_set(H_CNT_ABORT, ca);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   }
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_army(A.army + (size_t)env * army_dw);
-  b.store_rows(A.rows + (size_t)env * A.row_dw, lds, A.hs, types_dirty);
+  b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && lm_valid) {
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
              A.row_dw);
   uint32_t lm[MAXP][MPASS];
   b.legal_masks(lm);
@@ -264,24 +264,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     b.chg = b.vch = b.gen = b.city = b.mtn = 0u;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) b.army[s] = 0;
-    b.tile_coords();
+    b.geometry();
   } else {
-    load_board(b, hdr, rows, army, lds, A.hs, A.row_dw);
+    load_board(b, hdr, rows, army, lds, A.fd, A.row_dw);
   }
 
-  const bool row_on = lane < b.H;
-  const int row0 = lane * b.W;
+  // per-tile source planes are read coalesced in the tile domain (lane l, slot s = tile 64s+l);
+  // each predicate becomes a flat plane through the wave ballot
   bool bad_owner = false;
   if (A.s_owner) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) b.own[p] = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) {
-        const int o = A.s_owner[to + row0 + x];
-        bad_owner |= (o < -1) || (o >= b.P);
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) b.own[p] |= (o == p) ? (1u << x) : 0u;
-      }
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const int o = (t < b.N) ? (int)A.s_owner[to + t] : -1;
+      bad_owner |= (o < -1) || (o >= b.P);
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) b.scatter(b.own[p], __builtin_amdgcn_ballot_w64(o == p), s);
+    }
   }
   if (wave_any(bad_owner)) {
     if (lane == 0) atomicExch(A.status, GVEC_E_BOARD);
@@ -289,43 +290,52 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   }
   if (A.s_type) {
     b.gen = b.city = b.mtn = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) {
-        const int ty = A.s_type[to + row0 + x];
-        b.gen |= (ty == GVEC_TILE_GENERAL) ? (1u << x) : 0u;
-        b.city |= (ty == GVEC_TILE_CITY) ? (1u << x) : 0u;
-        b.mtn |= (ty == GVEC_TILE_MOUNTAIN) ? (1u << x) : 0u;
-      }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const int ty = (t < b.N) ? (int)A.s_type[to + t] : GVEC_TILE_NORMAL;
+      b.scatter(b.gen, __builtin_amdgcn_ballot_w64(ty == GVEC_TILE_GENERAL), s);
+      b.scatter(b.city, __builtin_amdgcn_ballot_w64(ty == GVEC_TILE_CITY), s);
+      b.scatter(b.mtn, __builtin_amdgcn_ballot_w64(ty == GVEC_TILE_MOUNTAIN), s);
+    }
   }
   if (A.s_visible) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) b.vis[p] = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) {
-        const uint32_t v = A.s_visible[to + row0 + x];
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) b.vis[p] |= ((v >> p) & 1u) << x;
-      }
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const uint32_t v = (t < b.N) ? (uint32_t)A.s_visible[to + t] : 0u;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) b.scatter(b.vis[p], __builtin_amdgcn_ballot_w64(((v >> p) & 1u) != 0u), s);
+    }
   }
   if (A.s_listed) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) b.lst[p] = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) {
-        const int o = A.s_listed[to + row0 + x];
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) b.lst[p] |= (o == p) ? (1u << x) : 0u;
-      }
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const int o = (t < b.N) ? (int)A.s_listed[to + t] : -1;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) b.scatter(b.lst[p], __builtin_amdgcn_ballot_w64(o == p), s);
+    }
   }
   if (A.s_changed) {
     b.chg = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) b.chg |= (A.s_changed[to + row0 + x] ? 1u : 0u) << x;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      b.scatter(b.chg, __builtin_amdgcn_ballot_w64(t < b.N && A.s_changed[to + t] != 0), s);
+    }
   }
   if (A.s_vis_changed) {
     b.vch = 0u;
-    if (row_on)
-      for (int x = 0; x < b.W; ++x) b.vch |= (A.s_vis_changed[to + row0 + x] ? 1u : 0u) << x;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      b.scatter(b.vch, __builtin_amdgcn_ballot_w64(t < b.N && A.s_vis_changed[to + t] != 0), s);
+    }
   }
   if (A.s_army) {
 #pragma unroll
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   if (A.init) b.initial_setup();
   b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_army(army);
-  b.store_rows(rows, lds, A.hs, true);
+  b.store_planes(rows, lds, A.fd, true);
 }
 
 // =========================================================================================
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
   uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.hs,
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
              A.row_dw);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
   const uint32_t special = b.gen | b.city | b.mtn;
@@ -582,8 +592,8 @@ __global__ void selftest_kernel(int32_t* out) {
   const int lane = lane_id();
   int fail = 0;
   const uint32_t v = (uint32_t)(lane * 3 + 1);
-  if (from_above(v) != (lane == 0 ? 0u : (uint32_t)((lane - 1) * 3 + 1))) fail = 1;
-  if (from_below(v) != (lane == 63 ? 0u : (uint32_t)((lane + 1) * 3 + 1))) fail = fail ? fail : 2;
+  if (from_prev(v) != (lane == 0 ? 0u : (uint32_t)((lane - 1) * 3 + 1))) fail = 1;
+  if (from_next(v) != (lane == 63 ? 0u : (uint32_t)((lane + 1) * 3 + 1))) fail = fail ? fail : 2;
   uint32_t expect = 0u;
   for (int l = 0; l <= lane; ++l) expect += (uint32_t)(l * 3 + 1);
   if (wave_scan_add(v) != expect) fail = fail ? fail : 3;

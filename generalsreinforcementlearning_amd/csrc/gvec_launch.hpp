@@ -36,7 +36,7 @@ struct ImportArgs {
   const uint8_t* s_alive;
   const int32_t* s_army_count;
   const int32_t* s_general_idx;
-  int32_t stride, max_p, max_w, max_h, hs, row_dw;
+  int32_t stride, max_p, max_w, max_h, fd, row_dw;
   uint32_t fresh;  // 1: start from a blank engine (reset); 0: poke the resident record
   uint32_t init;   // 1: run performInitialSetup after the import
   uint32_t fog;
@@ -69,7 +69,7 @@ struct ExportArgs {
   int32_t vis_player;
   uint8_t* pv_visible;
   uint8_t* pv_fog;
-  int32_t stride, max_p, hs, row_dw;
+  int32_t stride, max_p, fd, row_dw;
 };
 
 struct MapgenArgs {
