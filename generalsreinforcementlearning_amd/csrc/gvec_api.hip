@@ -587,15 +587,12 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
   a.invalid_permille = invalid_permille;
   if (fused) {
     a.turns = turns;
-    if (h->legal_valid) a.flags |= KF_LMVALID;
-    if (turns > 0) HIPCHK(launch_step(h->var, a, h->stream));
-  } else {
+    if (turns > 0) HIPCHK(launch_rollout(h->var, a, h->stream));
+  } else if (turns > 0) {
+    if (!h->legal_valid) RET_IF(refresh_legal(h));  // the per-turn agent samples from the mask buffer
     a.turns = 1;
-    for (int k = 0; k < turns; ++k) {
-      if (h->legal_valid) a.flags |= KF_LMVALID;
-      HIPCHK(launch_step(h->var, a, h->stream));
-      h->legal_valid = true;
-    }
+    a.flags |= KF_LMVALID;
+    for (int k = 0; k < turns; ++k) HIPCHK(launch_step(h->var, a, h->stream));
   }
   if (turns > 0) h->legal_valid = true;
   if (stats) {

@@ -98,7 +98,50 @@ __device__ __forceinline__ uint32_t* wave_lds(uint32_t* smem, int wave, int row_
   return base;
 }
 
+// vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
 template <int MAXP, int NSLOT>
+__device__ __forceinline__ void redeal(Board<MAXP, NSLOT>& b, const StepArgs& A, int env, uint32_t* lds) {
+  const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
+  const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
+  const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
+  const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
+  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * NSLOT * 64, lds, A.fd,
+             A.row_dw);
+  b.hdr_set(H_EPISODE, episode);
+  b.hdr_set(H_CNT_STEPS, cs);
+  b.hdr_set(H_CNT_ABORT, ca);
+  b.hdr_set(H_CNT_DONE, cd);
+}
+
+template <int MAXP, int NSLOT>
+using Masks = uint32_t[MAXP][Board<MAXP, NSLOT>::MPASS];
+
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void load_masks(Masks<MAXP, NSLOT>& lm, const StepArgs& A, int env) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+    for (int q = 0; q < Board<MAXP, NSLOT>::MPASS; ++q) {
+      const int j = lane + 64 * q;
+      lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
+    }
+}
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void store_masks(const Masks<MAXP, NSLOT>& lm, const StepArgs& A, int env) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+    for (int q = 0; q < Board<MAXP, NSLOT>::MPASS; ++q) {
+      const int j = lane + 64 * q;
+      if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
+    }
+}
+
+// ONE engine turn per launch, straight-line (gvec_step; per-turn rollouts).  AGENT: actions are
+// sampled on device from the legal-mask buffer, which the host guarantees to be current.
+template <int MAXP, int NSLOT, bool AGENT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
@@ -111,55 +154,23 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   const size_t army_dw = (size_t)NSLOT * 64;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.fd,
              A.row_dw);
-
+  const bool emit = (A.flags & KF_EMIT) != 0u;
   uint32_t lm[MAXP][MPASS];
-  const bool agent = (A.flags & KF_AGENT) != 0u, emit = (A.flags & KF_EMIT) != 0u;
-  bool lm_valid = false, types_dirty = false;
-  if (agent && (A.flags & KF_LMVALID)) {
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-      for (int q = 0; q < MPASS; ++q) {
-        const int j = lane + 64 * q;
-        lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
-      }
-    lm_valid = true;
-  }
-  uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
-  const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
-
-  for (int k = 0;; ++k) {
-    // the masks of the CURRENT state: input of the agent, and the output after the last turn
-    if (!lm_valid && (agent || emit) && (agent || k == A.turns)) {
-      b.legal_masks(lm);
-      lm_valid = true;
-    }
-    if (k >= A.turns) break;
-    if (b.hflags & HF_DONE) {
-      if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
-        // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
-        const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
-        const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
-        const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
-        const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
-        load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * army_dw, lds,
-                   A.fd, A.row_dw);
-        b.hdr_set(H_EPISODE, episode);
-        b.hdr_set(H_CNT_STEPS, cs);
-        b.hdr_set(H_CNT_ABORT, ca);
-        b.hdr_set(H_CNT_DONE, cd);
-        types_dirty = true;
-        lm_valid = false;
-        err = 0u;
-        continue;
-      }
+  uint32_t err = 0u;
+  bool types_dirty = false, changed = true;
+  if (b.hflags & HF_DONE) {
+    if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
+      redeal<MAXP, NSLOT>(b, A, env, lds);
+      types_dirty = true;
+    } else {
       err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
-      k = A.turns - 1;           // nothing more will happen in this launch
-      continue;
+      changed = false;
     }
+  } else {
     uint32_t alo = 0u, ahi = 0u;
-    if (agent) {
-      agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+    if constexpr (AGENT) {
+      load_masks<MAXP, NSLOT>(lm, A, env);
+      agent_sample<MAXP, NSLOT>(b, lm, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
       if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
     } else if (lane < A.pstride) {
       const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
@@ -168,30 +179,68 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
     }
     bool aborted;
     err = b.turn_step(alo, ahi, A, aborted);
-    lm_valid = false;
-    n_steps += 1u;
-    n_abort += aborted ? 1u : 0u;
-    n_done += (b.hflags & HF_DONE) ? 1u : 0u;
-  }
-  {
-    const uint32_t cs = b.hdr_get(H_CNT_STEPS) + n_steps, ca = b.hdr_get(H_CNT_ABORT) + n_abort, cd = b.hdr_get(H_CNT_DONE) + n_done;
-    b.hdr_set(H_CNT_STEPS, cs);
-    b.hdr_set(H_CNT_ABORT, ca);
-    b.hdr_set(H_CNT_DONE, cd);
+    b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
+    if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
+    if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
   }
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_army(A.army + (size_t)env * army_dw);
   b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
-  if (emit && lm_valid) {
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-      for (int q = 0; q < MPASS; ++q) {
-        const int j = lane + 64 * q;
-        if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
-      }
+  if (emit && (changed || !(A.flags & KF_LMVALID))) {
+    b.legal_masks(lm);
+    store_masks<MAXP, NSLOT>(lm, A, env);
   }
+}
+
+// `turns` engine turns per launch with the board kept in registers / LDS (fused rollouts; always
+// with the on-device agent)
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rollout_kernel(StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  constexpr int MPASS = B::MPASS;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  B b;
+  uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
+  const size_t army_dw = (size_t)NSLOT * 64;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.fd,
+             A.row_dw);
+  uint32_t lm[MAXP][MPASS];
+  bool types_dirty = false;
+  uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
+  const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
+  for (int k = 0;; ++k) {
+    b.legal_masks(lm);  // the masks of the CURRENT state: input of the agent, output after the last turn
+    if (k >= A.turns) break;
+    if (b.hflags & HF_DONE) {
+      if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
+        redeal<MAXP, NSLOT>(b, A, env, lds);
+        types_dirty = true;
+        err = 0u;
+        continue;
+      }
+      err = GVEC_ERR_GAME_OVER;  // frozen for the rest of the launch
+      break;
+    }
+    uint32_t alo, ahi;
+    agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+    bool aborted;
+    err = b.turn_step(alo, ahi, A, aborted);
+    n_steps += 1u;
+    n_abort += aborted ? 1u : 0u;
+    n_done += (b.hflags & HF_DONE) ? 1u : 0u;
+  }
+  b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + n_steps);
+  b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + n_abort);
+  b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + n_done);
+  b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
+  b.store_army(A.army + (size_t)env * army_dw);
+  b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
+  if (A.err && lane == 0) A.err[env] = (int32_t)err;
+  store_masks<MAXP, NSLOT>(lm, A, env);
 }
 
 // legal masks / agent actions of the resident state (no turn is played)
@@ -647,8 +696,18 @@ static inline size_t wave_lds(int row_dw) { return (size_t)WAVES_PER_BLOCK * (si
 
 hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
-    hipLaunchKernelGGL((step_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw + decltype(S_)::value * 64), s, a);
+    constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
+    if (a.flags & KF_AGENT)
+      hipLaunchKernelGGL((step_kernel<P, S, true>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
+    else
+      hipLaunchKernelGGL((step_kernel<P, S, false>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
+    hipLaunchKernelGGL((rollout_kernel<P, S>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
     return hipGetLastError();
   });
 }

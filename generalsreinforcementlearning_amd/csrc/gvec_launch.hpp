@@ -87,7 +87,10 @@ struct MapgenArgs {
   int32_t* status;
 };
 
+// one turn per launch (KF_AGENT selects the on-device agent; the legal buffer must then be current)
 hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s);
+// a.turns fused turns per launch with the on-device agent
+hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s);
