@@ -66,12 +66,9 @@ def lib_path():
     return os.path.join(_PKG, "libgvec_hip.so")
 
 
-def load():
-    """Loads the HIP library.  Fails loudly if it has not been built: there is no fallback."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = lib_path()
+def load_from(path):
+    """Loads one build of the HIP library from `path` (not cached: A/B benchmarking of two builds
+    in one process uses this directly)."""
     if not os.path.exists(path):
         raise GvecError(-2, f"{path} not found: build it with `python generalsreinforcementlearning_amd/csrc/build.py` "
                             "(hipcc, gfx950). This package has no CPU fallback.")
@@ -82,16 +79,23 @@ def load():
         fn.argtypes = args
     if L.gvec_abi_version() != 1:
         raise GvecError(-1, "ABI version mismatch")
-    _LIB = L
     return L
+
+
+def load():
+    """Loads the HIP library.  Fails loudly if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        _LIB = load_from(lib_path())
+    return _LIB
 
 
 def lib():
     return load()
 
 
-def check(rc, what=""):
+def check(rc, what="", L=None):
     if rc < 0:
-        msg = load().gvec_last_error()
+        msg = (L or load()).gvec_last_error()
         raise GvecError(rc, f"{what}: {msg.decode() if msg else ''}")
     return rc

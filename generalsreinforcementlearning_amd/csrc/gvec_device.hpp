@@ -132,6 +132,21 @@ __device__ __forceinline__ uint32_t env_key(uint32_t lo, uint32_t hi, uint32_t e
   return fmix32(fmix32(lo ^ 0x9E3779B9u) + hi * 0x85EBCA77u + env * 0xC2B2AE3Du + 0x27D4EB2Fu);
 }
 
+// kColumnPattern[W] = sum of 1 << k for k = 0, W, 2W, ... < 32: where column 0 falls in a 32-tile
+// window that starts in column 0
+struct ColumnPatternTable {
+  uint32_t v[33];
+  constexpr ColumnPatternTable() : v{} {
+    for (int w = 1; w <= 32; ++w) {
+      uint32_t p = 0u;
+      for (int k = 0; k < 32; k += w) p |= 1u << k;
+      v[w] = p;
+    }
+  }
+  __device__ __forceinline__ uint32_t operator[](int w) const { return v[w]; }
+};
+__device__ const ColumnPatternTable kColumnPattern{};
+
 // spread bit i of the low byte to bit 4*i
 __device__ __forceinline__ uint32_t spread4(uint32_t x) {
   x &= 0xFFu;
@@ -167,8 +182,7 @@ struct Board {
     const int t0 = 32 * (lane_id() & 31);
     const int left = N - t0;
     valid = (lane_id() >= 32 || left <= 0) ? 0u : (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
-    uint32_t pat = 0u;  // bits at multiples of W below 32 (wave-uniform, <= 32/W + 1 iterations)
-    for (int k = 0; k < 32; k += W) pat |= 1u << k;
+    const uint32_t pat = kColumnPattern[W];  // bits at multiples of W below 32 (one scalar load)
     const int q = (t0 * recipW) >> 16;  // t0 / W, exact for t0 < 1024
     const int x0 = t0 - q * W;          // column of this lane's first tile
     const uint32_t col0 = pat << (x0 ? W - x0 : 0);
@@ -271,6 +285,8 @@ struct Board {
     wave_lds_fence();
   }
 
+  // whole 64-tile slots travel both ways (the padding beyond N holds zeros).  Trimming the store to
+  // the board's N tiles was measured 4 % SLOWER: it turns the last slot into partial-line writes.
   __device__ __forceinline__ void load_army(const int32_t* army_env) {
     const int lane = lane_id();
 #pragma unroll

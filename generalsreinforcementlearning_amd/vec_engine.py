@@ -58,8 +58,8 @@ class VecEngine:
     """B independent engines stepped by one HIP launch (one wavefront per board)."""
 
     def __init__(self, num_envs, width, height, players, fog_of_war=True, device=0, production=(1, 1, 1),
-                 normal_growth_interval=25, auto_reset=False, stream=None):
-        self.L = _lib.load()
+                 normal_growth_interval=25, auto_reset=False, stream=None, lib=None):
+        self.L = lib if lib is not None else _lib.load()
         cfg = Config()
         check(self.L.gvec_config_default(C.byref(cfg)))
         cfg.num_envs, cfg.max_width, cfg.max_height, cfg.max_players = num_envs, width, height, players
