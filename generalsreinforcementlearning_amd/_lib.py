@@ -55,6 +55,10 @@ SYMBOLS = {
     "gvec_write_state": (_i32, [_vp, _i32, _i32, C.POINTER(StateView), _i32]),
     "gvec_rollout": (_i32, [_vp, _i32, _u64, _i32, _i32, C.POINTER(RolloutStats)]),
     "gvec_agent_actions": (_i32, [_vp, _u64, _i32, _vp, _i32]),
+    "gvec_experience_begin": (_i32, [_vp]),
+    "gvec_experience_rewards": (_i32, [_vp, _vp, _vp, _i32]),
+    "gvec_observe": (_i32, [_vp, _i32, _vp, _i32]),
+    "gvec_serializer_mask": (_i32, [_vp, _vp, _i32]),
     "gvec_export_records": (_i32, [_vp, _i32, _i32, _vp]),
     "gvec_import_records": (_i32, [_vp, _i32, _i32, _vp]),
     "gvec_device_buffer": (_vp, [_vp, _i32]),

@@ -43,6 +43,8 @@ struct gvec_handle {
   int32_t* d_err = nullptr;
   int32_t* d_status = nullptr;
   unsigned long long* d_counters = nullptr;  // [6]: before[3], after[3]
+  uint32_t* d_snap = nullptr;                // experience snapshots [B][snap_dw] (allocated on first use)
+  int snap_dw = 0;
   uint32_t* p_hdr = nullptr;
   uint32_t* p_rows = nullptr;
   int32_t* p_army = nullptr;
@@ -294,7 +296,7 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
 int32_t gvec_destroy(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters, h->p_hdr, h->p_rows, h->p_army};
+  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters, h->d_snap, h->p_hdr, h->p_rows, h->p_army};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -622,6 +624,82 @@ int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permil
                           h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
+  return GVEC_OK;
+}
+
+static ExperienceArgs exp_args(gvec_handle* h) {
+  ExperienceArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army = h->d_army;
+  a.snap = h->d_snap;
+  a.num_envs = h->cfg.num_envs;
+  a.fd = h->fd;
+  a.row_dw = h->row_dw;
+  a.snap_dw = h->snap_dw;
+  a.pstride = h->maxp;
+  a.stride = h->stride;
+  a.player = -1;
+  return a;
+}
+
+int32_t gvec_experience_begin(gvec_handle* h) {
+  if (!h) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->d_snap) {
+    h->snap_dw = (int)round_up((size_t)h->var.maxp * h->fd + 2 * h->var.maxp + 2, 4);
+    HIPCHK(hipMalloc(&h->d_snap, (size_t)h->cfg.num_envs * h->snap_dw * 4));
+  }
+  HIPCHK(launch_snapshot(h->var, exp_args(h), h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, int32_t mem) {
+  if (!h || !rewards) return GVEC_E_INVALID;
+  if (!h->d_snap) {
+    set_err("gvec_experience_rewards without a preceding gvec_experience_begin");
+    return GVEC_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->cfg.num_envs;
+  DevBuf br, bd;
+  ExperienceArgs a = exp_args(h);
+  RET_IF(stage_out(br, rewards, B * h->maxp, mem, &a.rewards));
+  RET_IF(stage_out(bd, done, B, mem, &a.done));
+  HIPCHK(launch_rewards(h->var, a, h->stream));
+  RET_IF(copy_out(h, br, rewards, B * h->maxp, mem));
+  RET_IF(copy_out(h, bd, done, B, mem));
+  if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
+  if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t count = (size_t)h->cfg.num_envs * (player < 0 ? h->maxp : 1) * 9 * h->stride;
+  DevBuf bo;
+  ExperienceArgs a = exp_args(h);
+  a.player = player;
+  RET_IF(stage_out(bo, out, count, mem, &a.obs));
+  HIPCHK(launch_observe(h->var, a, h->stream));
+  RET_IF(copy_out(h, bo, out, count, mem));
+  if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem) {
+  if (!h || !bits) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t bytes = (size_t)h->cfg.num_envs * h->maxp * h->mask_bytes;
+  DevBuf bb;
+  StepArgs a = base_args(h);
+  uint8_t* dst = nullptr;
+  RET_IF(stage_out(bb, bits, bytes, mem, &dst));
+  a.legal = reinterpret_cast<uint32_t*>(dst);
+  HIPCHK(launch_serializer_mask(h->var, a, h->stream));
+  RET_IF(copy_out(h, bb, bits, bytes, mem));
+  if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
   return GVEC_OK;
 }
 

@@ -586,6 +586,10 @@ struct Board {
     const int j = lane_id() + 64 * pass;
     return __builtin_amdgcn_ubfe(bperm((j >> 2) << 2, plane), (uint32_t)(8 * (j & 3)), 8u);
   }
+  // SERIALIZER = false: Engine.GetLegalActionMask (rules/legal_moves.go:19-73).
+  // SERIALIZER = true : Serializer.GenerateActionMask (internal/experience/serializer.go:112-176):
+  //   board owner (not the list), army >= 2, no Alive check, directions 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
+  template <bool SERIALIZER = false>
   __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS]) const {
     uint32_t gt1 = 0u;  // army > 1 as a flat plane
 #pragma unroll
@@ -595,17 +599,29 @@ struct Board {
     const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;  // target x+1 / x-1
 #pragma unroll
     for (int k = 0; k < MPASS; ++k) {
-      const uint32_t okn = spread4(flat_byte(ok_up, k)) | (spread4(flat_byte(ok_rt, k)) << 1) |
-                           (spread4(flat_byte(ok_dn, k)) << 2) | (spread4(flat_byte(ok_lf, k)) << 3);
+      const uint32_t s_up = spread4(flat_byte(ok_up, k)), s_rt = spread4(flat_byte(ok_rt, k));
+      const uint32_t s_dn = spread4(flat_byte(ok_dn, k)), s_lf = spread4(flat_byte(ok_lf, k));
+      const uint32_t okn = SERIALIZER ? (s_up | (s_dn << 1) | (s_lf << 2) | (s_rt << 3)) : (s_up | (s_rt << 1) | (s_dn << 2) | (s_lf << 3));
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
-        // :26-28 alive, :37 listed, :41 owner == pid && army > 1
-        const uint32_t cb = flat_byte(lst[p] & own[p] & gt1, k);  // cross-lane: keep it unconditional
-        const uint32_t can = ((alive >> p) & 1u) ? cb : 0u;
+        // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1
+        const uint32_t src = SERIALIZER ? (own[p] & gt1) : (lst[p] & own[p] & gt1);
+        const uint32_t cb = flat_byte(src, k);  // cross-lane: keep it unconditional
+        const uint32_t can = (SERIALIZER || ((alive >> p) & 1u)) ? cb : 0u;
         out[p][k] = (spread4(can) * 15u) & okn;
       }
     }
   }
+
+  // ---- internal/experience/rewards.go helpers ---------------------------------------------------
+  // sum of Tile.Army over a flat plane (countPlayerArmies, rewards.go:98-107)
+  __device__ __forceinline__ int32_t army_sum(uint32_t plane) const {
+    int32_t acc = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc += army[s] & gather_mask(plane, s);
+    return (int32_t)wave_sum((uint32_t)acc);
+  }
+  __device__ __forceinline__ int32_t count(uint32_t plane) const { return (int32_t)wave_sum((uint32_t)__builtin_popcount(plane)); }
 };
 
 }  // namespace gvec

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
-    b.legal_masks(lm);
+    b.template legal_masks<false>(lm);
     store_masks<MAXP, NSLOT>(lm, A, env);
   }
 }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rollout_kernel(StepArgs 
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
   for (int k = 0;; ++k) {
-    b.legal_masks(lm);  // the masks of the CURRENT state: input of the agent, output after the last turn
+    b.template legal_masks<false>(lm);  // the masks of the CURRENT state: input of the agent, output after the last turn
     if (k >= A.turns) break;
     if (b.hflags & HF_DONE) {
       if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rollout_kernel(StepArgs 
 }
 
 // legal masks / agent actions of the resident state (no turn is played)
-template <int MAXP, int NSLOT, bool AGENT>
+// MODE 0: Engine.GetLegalActionMask   1: random-agent actions   2: Serializer.GenerateActionMask
+template <int MAXP, int NSLOT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
@@ -258,8 +259,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
              A.row_dw);
   uint32_t lm[MAXP][MPASS];
-  b.legal_masks(lm);
-  if (AGENT) {
+  if constexpr (MODE == 2) b.template legal_masks<true>(lm);
+  else b.template legal_masks<false>(lm);
+  if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
     if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
@@ -271,6 +273,152 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
         const int j = lane + 64 * q;
         if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
       }
+  }
+}
+
+// =========================================================================================
+// internal/experience: snapshot (GameState.Clone before the step), rewards, observation tensor
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(ExperienceArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
+  B b;
+  b.larmy = nullptr;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
+             A.row_dw);
+  uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
+  uint32_t tail = 0u;  // lane p: territory, lane MAXP+p: armies, lane 2*MAXP: turn, +1: W|H<<8
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (lane < A.fd) sn[p * A.fd + lane] = b.own[p];
+    const int32_t terr = b.count(b.own[p]), arm = b.army_sum(b.own[p]);
+    tail = (lane == p) ? (uint32_t)terr : tail;
+    tail = (lane == MAXP + p) ? (uint32_t)arm : tail;
+  }
+  tail = (lane == 2 * MAXP) ? (uint32_t)b.turn : tail;
+  tail = (lane == 2 * MAXP + 1) ? ((uint32_t)b.W | ((uint32_t)b.H << 8)) : tail;
+  if (lane < 2 * MAXP + 2) sn[MAXP * A.fd + lane] = tail;
+}
+
+// CalculateRewardWithConfig (internal/experience/rewards.go:45-85) with DefaultRewardConfig (:23-37);
+// prev = the snapshot, cur = the resident state.  float32 arithmetic in the reference's order,
+// compiled with -ffp-contract=off (Go on amd64 does not fuse multiply-add).
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(ExperienceArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
+  B b;
+  b.larmy = nullptr;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
+             A.row_dw);
+  const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
+  const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[MAXP * A.fd + lane] : 0u;
+  const int prev_turn = (int)rdlane(tail, 2 * MAXP);
+  const uint32_t prev_dims = rdlane(tail, 2 * MAXP + 1);
+  // a board re-dealt by auto-reset (or not stepped) has no meaningful predecessor: reward 0
+  const bool comparable = prev_dims == ((uint32_t)b.W | ((uint32_t)b.H << 8)) && b.turn > prev_turn;
+  const int na = __builtin_popcount(b.alive);
+  const bool over = na <= 1;                                     // GameState.IsGameOver (state.go:73-82)
+  const int winner = (na == 1) ? (31 - __builtin_clz(b.alive)) : -1;  // GameState.GetWinner (state.go:85-100)
+  uint32_t prev_own[MAXP], prev_any = 0u;
+  int32_t cur_arm[MAXP], total = 0;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    prev_own[p] = (lane < A.fd) ? sn[p * A.fd + lane] : 0u;
+    prev_any |= prev_own[p];
+    cur_arm[p] = b.army_sum(b.own[p]);
+    total += cur_arm[p];
+  }
+  float rv = 0.0f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int d_terr = b.count(b.own[p]) - (int)rdlane(tail, p);             // :59-62
+    const int d_arm = cur_arm[p] - (int)rdlane(tail, MAXP + p);               // :65-68
+    const int c_gain = b.count(b.city & b.own[p] & ~prev_own[p]);             // countCityChanges :110-129
+    const int c_lost = b.count(b.city & prev_own[p] & ~b.own[p]);
+    const int g_gain = b.count(b.gen & b.own[p] & ~prev_own[p] & prev_any);   // countGeneralChanges :132-151
+    const int g_lost = b.count(b.gen & prev_own[p] & ~b.own[p]);
+    float r = 0.0f;
+    r += (float)d_terr * 0.01f;
+    r += (float)d_arm * 0.001f;
+    r += (float)c_gain * 0.1f;
+    r += (float)c_lost * -0.1f;
+    r += (float)g_gain * 0.5f;
+    r += (float)g_lost * -0.5f;
+    const int pa = cur_arm[p], ea = total - cur_arm[p];                       // calculateArmyAdvantage :153-175
+    const float adv = (total == 0) ? 0.0f : ((float)(pa - ea) / (float)total);
+    r += adv * 0.05f;
+    if (over && winner == p) r = 1.0f;                                        // :49-56
+    else if (over && winner != -1) r = -1.0f;
+    r = (comparable && p < b.P) ? r : 0.0f;
+    rv = (lane == p) ? r : rv;
+  }
+  if (lane < A.pstride) A.rewards[(size_t)env * A.pstride + lane] = rv;
+  if (A.done && lane == 0) A.done[env] = (uint8_t)(over ? 1 : 0);
+}
+
+// Serializer.StateToTensor (internal/experience/serializer.go:37-109): [9][H][W] float32 from one
+// player's perspective; the output is 9 coalesced channel planes per 64-tile slot.
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(ExperienceArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
+  B b;
+  b.larmy = nullptr;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
+             A.row_dw);
+  const bool fog_on = (b.hflags & HF_FOG) != 0u;
+  uint32_t own_any = 0u;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) own_any |= b.own[p];
+  const uint32_t special = b.gen | b.city;
+  const int p_lo = (A.player < 0) ? 0 : A.player, p_hi = (A.player < 0) ? A.pstride : A.player + 1;
+  for (int pl = p_lo; pl < p_hi; ++pl) {
+    float* out = A.obs + ((A.player < 0) ? ((size_t)env * A.pstride + pl) : (size_t)env) * 9 * (size_t)A.stride;
+    uint32_t own_p = 0u, vis_p = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      own_p = (p == pl) ? b.own[p] : own_p;
+      vis_p = (p == pl) ? b.vis[p] : vis_p;
+    }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const bool mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u, seen = b.gather(vis_p, s) != 0u;
+      const bool spec = b.gather(special, s) != 0u, mount = b.gather(b.mtn, s) != 0u;
+      const bool visible = !fog_on || seen;  // :50
+      const bool open = visible && !mount;   // mountains short-circuit (:68-71)
+      float norm = (float)b.army[s] / 1000.0f;  // :82-85
+      norm = norm > 1.0f ? 1.0f : norm;
+      const float arm = (b.army[s] > 0) ? norm : 0.0f;
+      if (t < b.N) {
+        const size_t n = (size_t)b.N;
+        out[0 * n + t] = (open && mine) ? arm : 0.0f;
+        out[1 * n + t] = (open && !mine && owned) ? arm : 0.0f;
+        out[2 * n + t] = (open && mine) ? 1.0f : 0.0f;
+        out[3 * n + t] = (open && !mine && owned) ? 1.0f : 0.0f;
+        out[4 * n + t] = (open && !owned) ? 1.0f : 0.0f;
+        out[5 * n + t] = (open && spec) ? 1.0f : 0.0f;
+        out[6 * n + t] = (visible && mount) ? 1.0f : 0.0f;
+        out[7 * n + t] = visible ? 1.0f : 0.0f;
+        out[8 * n + t] = visible ? 0.0f : 1.0f;
+      }
+    }
+    // a smaller board in a padded batch: clear the rest of the slot
+    for (int i = 9 * b.N + lane; i < 9 * A.stride; i += 64) out[i] = 0.0f;
   }
 }
 
@@ -713,15 +861,43 @@ hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s) {
 }
 hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
-    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, true>), wave_grid(a.num_envs),
+    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 1>), wave_grid(a.num_envs),
                        dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
-    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, false>), wave_grid(a.num_envs),
+    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 0>), wave_grid(a.num_envs),
                        dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_serializer_mask(const Variant& v, const StepArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 2>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((snapshot_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((rewards_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((observe_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       wave_lds(a.row_dw), s, a);
     return hipGetLastError();
   });
 }

@@ -93,6 +93,22 @@ hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s);
 hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s);
+hipError_t launch_serializer_mask(const Variant& v, const StepArgs& a, hipStream_t s);
+
+// internal/experience side channel
+struct ExperienceArgs {
+  const uint32_t* hdr;
+  const uint32_t* rows;
+  const int32_t* army;
+  uint32_t* snap;     // [B][snap_dw]: prev own planes, territory[MAXP], armies[MAXP], turn, W|H<<8
+  float* rewards;     // [B][pstride]
+  uint8_t* done;      // [B] or null
+  float* obs;         // observe: [B][9*stride] (one player) or [B][pstride][9*stride] (player = -1)
+  int32_t num_envs, fd, row_dw, snap_dw, pstride, stride, player;
+};
+hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s);
+hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s);
+hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s);
 hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s);
 hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s);

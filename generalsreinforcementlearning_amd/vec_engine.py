@@ -195,6 +195,31 @@ class VecEngine:
               "gvec_rollout")
         return {"env_steps": st.env_steps, "aborted_turns": st.aborted_turns, "games_finished": st.games_finished} if want_stats else None
 
+    # ---- internal/experience side channel (serializer.go, rewards.go) --------------------------------
+    def experience_begin(self):
+        """TurnProcessor.captureStateForExperience (turn_processor.go:116-121): snapshot before the step."""
+        check(self.L.gvec_experience_begin(self.h), "gvec_experience_begin")
+
+    def experience_rewards(self):
+        """CalculateReward(prev snapshot, current, player) -> (rewards[B][P] float32, done[B] bool)."""
+        r = np.zeros((self.B, self.max_p), np.float32)
+        d = np.zeros(self.B, np.uint8)
+        check(self.L.gvec_experience_rewards(self.h, _ptr(r), _ptr(d), MEM_HOST), "gvec_experience_rewards")
+        return r, d.astype(bool)
+
+    def observe(self, player=-1):
+        """Serializer.StateToTensor: [B][9*stride] for one player, [B][P][9*stride] for player=-1."""
+        shape = (self.B, self.max_p, 9 * self.stride) if player < 0 else (self.B, 9 * self.stride)
+        out = np.zeros(shape, np.float32)
+        check(self.L.gvec_observe(self.h, player, _ptr(out), MEM_HOST), "gvec_observe")
+        return out
+
+    def serializer_mask_bits(self):
+        """Serializer.GenerateActionMask for all envs/players, packed like legal_action_mask_bits."""
+        bits = np.zeros((self.B, self.max_p, self.mask_bytes), np.uint8)
+        check(self.L.gvec_serializer_mask(self.h, _ptr(bits), MEM_HOST), "gvec_serializer_mask")
+        return bits
+
     # ---- experience gather support -----------------------------------------------------------------
     def state_bytes_per_env(self):
         return self.L.gvec_state_bytes_per_env(self.h)

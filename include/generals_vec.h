@@ -223,6 +223,30 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed,
 int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille,
                            gvec_action* actions, int32_t mem);
 
+/* ---- internal/experience side channel ------------------------------
+ * gvec_experience_begin   = TurnProcessor.captureStateForExperience
+ *                           (turn_processor.go:116-121: GameState.Clone before the step):
+ *                           snapshots what the reward needs from the current state.
+ * gvec_experience_rewards = CalculateReward(prev, cur, player) for every env / player
+ *                           (internal/experience/rewards.go:40-85, DefaultRewardConfig
+ *                           :23-37), prev = the snapshot, cur = the resident state;
+ *                           rewards[B][max_players] float32, done[B] =
+ *                           GameState.IsGameOver (state.go:73-82), may be NULL.  A board
+ *                           that was re-dealt since the snapshot gets reward 0.
+ * gvec_observe            = Serializer.StateToTensor(state, player)
+ *                           (internal/experience/serializer.go:37-109): float32
+ *                           [9][H][W] at index c*H*W + y*W + x inside a slot of
+ *                           9*tile_stride floats; player >= 0: out[B][9*stride];
+ *                           player = -1: out[B][max_players][9*stride].
+ * gvec_serializer_mask    = Serializer.GenerateActionMask (serializer.go:112-176):
+ *                           same packing as gvec_legal_mask but the serializer's
+ *                           semantics (board owner, army >= 2, no Alive check) and
+ *                           direction order 0 up, 1 down, 2 left, 3 right. */
+int32_t gvec_experience_begin(gvec_handle* h);
+int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, int32_t mem);
+int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
+int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
+
 /* ---- experience gather support ---------------------------------------
  * Copies the compact resident records of envs [env_begin, env_begin+n) into a
  * device buffer (e.g. a torch tensor handed to RCCL all_gather).  Record size:

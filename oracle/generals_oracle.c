@@ -516,6 +516,7 @@ const uint8_t* ora_engine_vis_changed(const ora_engine* e) { return e->vis_chang
 /* batch of engines                                                          */
 /* ------------------------------------------------------------------------- */
 struct ora_batch {
+  ora_engine** prev;    /* experience snapshots (GameState.Clone before the step) */
   int32_t num_envs, max_w, max_h, max_p, stride, mask_bytes;
   ora_params params;
   ora_engine** env;
@@ -535,7 +536,8 @@ ora_batch* ora_batch_new(int32_t num_envs, int32_t max_w, int32_t max_h, int32_t
 }
 void ora_batch_free(ora_batch* b) {
   if (!b) return;
-  for (int i = 0; i < b->num_envs; i++) ora_engine_free(b->env[i]);
+  for (int i = 0; i < b->num_envs; i++) { ora_engine_free(b->env[i]); if (b->prev) ora_engine_free(b->prev[i]); }
+  free(b->prev);
   free(b->env); free(b->episode); free(b->pool_w); free(b->pool_h); free(b->pool_p); free(b);
 }
 ora_engine* ora_batch_engine(ora_batch* b, int32_t env) { return b->env[env]; }
@@ -684,6 +686,170 @@ int32_t ora_batch_write_state(ora_batch* b, int32_t env_begin, int32_t n, const 
       }
     }
   }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* internal/experience: serializer.go, rewards.go                             */
+/* ------------------------------------------------------------------------- */
+ora_engine* ora_engine_clone(const ora_engine* e) { /* state.go:37-70 */
+  int n = e->board->w * e->board->h;
+  ora_engine* c = (ora_engine*)calloc(1, sizeof(ora_engine));
+  *c = *e;
+  c->board = ora_board_new(e->board->w, e->board->h);
+  memcpy(c->board->t, e->board->t, sizeof(ora_tile) * (size_t)n);
+  c->players = (ora_player*)calloc((size_t)(e->num_players > 0 ? e->num_players : 1), sizeof(ora_player));
+  for (int p = 0; p < e->num_players; p++) {
+    c->players[p] = e->players[p];
+    c->players[p].owned.v = NULL; c->players[p].owned.n = 0; c->players[p].owned.cap = 0;
+    for (int k = 0; k < e->players[p].owned.n; k++) ilist_push(&c->players[p].owned, e->players[p].owned.v[k]);
+  }
+  tset_init(&c->changed, n); tset_init(&c->vis_changed, n);
+  for (int t = 0; t < n; t++) { if (e->changed.bits[t]) tset_add(&c->changed, t); if (e->vis_changed.bits[t]) tset_add(&c->vis_changed, t); }
+  return c;
+}
+
+void ora_state_to_tensor(const ora_engine* e, int32_t player, float* out) { /* serializer.go:37-109 */
+  int w = e->board->w, h = e->board->h, n = w * h;
+  memset(out, 0, sizeof(float) * (size_t)(9 * n));
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int t = y * w + x;
+      const ora_tile* tile = &e->board->t[t];
+      int visible = !e->fog || ora_tile_is_visible_to(tile, player);   /* :50 */
+      if (visible) out[7 * n + t] = 1.0f;                               /* :53-55 */
+      if (!visible) { out[8 * n + t] = 1.0f; continue; }                /* :58-65 */
+      if (tile->type == ORA_TILE_MOUNTAIN) { out[6 * n + t] = 1.0f; continue; } /* :68-71 */
+      if (tile->type == ORA_TILE_CITY || tile->type == ORA_TILE_GENERAL) out[5 * n + t] = 1.0f; /* :74-76 */
+      if (tile->owner == player) {                                      /* :79-89 */
+        if (tile->army > 0) { float v = (float)tile->army / 1000.0f; if (v > 1.0f) v = 1.0f; out[0 * n + t] = v; }
+        out[2 * n + t] = 1.0f;
+      } else if (tile->owner >= 0) {                                    /* :90-100 */
+        if (tile->army > 0) { float v = (float)tile->army / 1000.0f; if (v > 1.0f) v = 1.0f; out[1 * n + t] = v; }
+        out[3 * n + t] = 1.0f;
+      } else {
+        out[4 * n + t] = 1.0f;                                          /* :101-104 */
+      }
+    }
+}
+
+void ora_serializer_mask(const ora_engine* e, int32_t player, uint8_t* mask) { /* serializer.go:112-176 */
+  int w = e->board->w, h = e->board->h;
+  memset(mask, 0, (size_t)(w * h * 4));
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const ora_tile* tile = &e->board->t[y * w + x];
+      if (tile->owner != player || tile->army < 2) continue;            /* :128-130 */
+      int base = (y * w + x) * 4;
+      if (y > 0 && e->board->t[(y - 1) * w + x].type != ORA_TILE_MOUNTAIN) mask[base + 0] = 1;     /* up :134-141 */
+      if (y < h - 1 && e->board->t[(y + 1) * w + x].type != ORA_TILE_MOUNTAIN) mask[base + 1] = 1; /* down :144-151 */
+      if (x > 0 && e->board->t[y * w + x - 1].type != ORA_TILE_MOUNTAIN) mask[base + 2] = 1;       /* left :154-161 */
+      if (x < w - 1 && e->board->t[y * w + x + 1].type != ORA_TILE_MOUNTAIN) mask[base + 3] = 1;   /* right :164-171 */
+    }
+}
+
+float ora_army_advantage(const ora_engine* e, int32_t player) { /* rewards.go:153-175 */
+  int n = e->board->w * e->board->h;
+  int64_t pa = 0, ea = 0;
+  for (int t = 0; t < n; t++) {
+    const ora_tile* tile = &e->board->t[t];
+    if (tile->owner == player) pa += tile->army; else if (tile->owner >= 0) ea += tile->army;
+  }
+  int64_t total = pa + ea;
+  if (total == 0) return 0.0f;
+  return (float)(pa - ea) / (float)total;
+}
+
+void ora_city_changes(const ora_engine* prev, const ora_engine* cur, int32_t player, int32_t* gained, int32_t* lost) { /* :110-129 */
+  int n = cur->board->w * cur->board->h; *gained = 0; *lost = 0;
+  for (int t = 0; t < n; t++) {
+    if (cur->board->t[t].type != ORA_TILE_CITY) continue;
+    int po = prev->board->t[t].owner, co = cur->board->t[t].owner;
+    if (po != player && co == player) (*gained)++;
+    if (po == player && co != player) (*lost)++;
+  }
+}
+
+float ora_calculate_reward(const ora_engine* prev, const ora_engine* cur, int32_t player) { /* rewards.go:45-85, config :23-37 */
+  const float WinGame = 1.0f, LoseGame = -1.0f, CaptureCity = 0.1f, LoseCity = -0.1f, CaptureGeneral = 0.5f, LoseGeneral = -0.5f,
+              TerritoryGained = 0.01f, ArmyGained = 0.001f, ArmyAdvantage = 0.05f;
+  volatile float reward = 0.0f; /* volatile: every += rounds to float32 like Go on amd64 (no fused multiply-add) */
+  { /* GameState.IsGameOver / GetWinner (state.go:73-100) */
+    int alive = 0, last = -1;
+    for (int p = 0; p < cur->num_players; p++) if (cur->players[p].alive) { alive++; last = cur->players[p].id; }
+    if (alive <= 1) {
+      int winner = (alive == 1) ? last : -1;
+      if (winner == player) return WinGame;
+      else if (winner != -1) return LoseGame;
+    }
+  }
+  int n = cur->board->w * cur->board->h;
+  int64_t pt = 0, ct = 0, pa = 0, ca = 0;
+  for (int t = 0; t < n; t++) {
+    if (prev->board->t[t].owner == player) { pt++; pa += prev->board->t[t].army; }   /* :87-107 */
+    if (cur->board->t[t].owner == player) { ct++; ca += cur->board->t[t].army; }
+  }
+  reward += (float)(ct - pt) * TerritoryGained;   /* :59-62 */
+  reward += (float)(ca - pa) * ArmyGained;        /* :65-68 */
+  int32_t cg, cl; ora_city_changes(prev, cur, player, &cg, &cl);
+  reward += (float)cg * CaptureCity;              /* :71-73 */
+  reward += (float)cl * LoseCity;
+  int gg = 0, gl = 0;                             /* countGeneralChanges :132-151 */
+  for (int t = 0; t < n; t++) {
+    if (cur->board->t[t].type != ORA_TILE_GENERAL) continue;
+    int po = prev->board->t[t].owner, co = cur->board->t[t].owner;
+    if (po != player && po >= 0 && co == player) gg++;
+    if (po == player && co != player) gl++;
+  }
+  reward += (float)gg * CaptureGeneral;           /* :76-78 */
+  reward += (float)gl * LoseGeneral;
+  reward += ora_army_advantage(cur, player) * ArmyAdvantage; /* :81-82 */
+  return reward;
+}
+
+int32_t ora_batch_experience_begin(ora_batch* b) {
+  if (!b->prev) b->prev = (ora_engine**)calloc((size_t)b->num_envs, sizeof(ora_engine*));
+  for (int i = 0; i < b->num_envs; i++) { ora_engine_free(b->prev[i]); b->prev[i] = b->env[i] ? ora_engine_clone(b->env[i]) : NULL; }
+  return 0;
+}
+int32_t ora_batch_rewards(ora_batch* b, float* rewards, uint8_t* done) {
+  if (!b->prev) return -1;
+  for (int i = 0; i < b->num_envs; i++) {
+    const ora_engine* cur = b->env[i]; const ora_engine* prev = b->prev[i];
+    int alive = 0;
+    for (int p = 0; p < cur->num_players; p++) alive += cur->players[p].alive ? 1 : 0;
+    if (done) done[i] = (uint8_t)(alive <= 1);   /* GameState.IsGameOver, state.go:73-82 */
+    for (int p = 0; p < b->max_p; p++) {
+      float r = 0.0f;
+      /* a board re-dealt by auto-reset has no meaningful predecessor: reward 0 */
+      if (p < cur->num_players && prev && prev->board->w == cur->board->w && prev->board->h == cur->board->h && cur->turn > prev->turn)
+        r = ora_calculate_reward(prev, cur, p);
+      rewards[(size_t)i * (size_t)b->max_p + p] = r;
+    }
+  }
+  return 0;
+}
+int32_t ora_batch_observe(ora_batch* b, int32_t player, float* out) {
+  for (int i = 0; i < b->num_envs; i++) {
+    float* o = out + (size_t)i * 9 * (size_t)b->stride;
+    memset(o, 0, sizeof(float) * 9 * (size_t)b->stride);
+    ora_state_to_tensor(b->env[i], player, o);
+  }
+  return 0;
+}
+int32_t ora_batch_serializer_mask(ora_batch* b, uint8_t* bits) {
+  uint8_t* scratch = (uint8_t*)malloc((size_t)b->stride * 4);
+  memset(bits, 0, (size_t)b->num_envs * (size_t)b->max_p * (size_t)b->mask_bytes);
+  for (int i = 0; i < b->num_envs; i++) {
+    const ora_engine* e = b->env[i];
+    int n4 = e->board->w * e->board->h * 4;
+    for (int p = 0; p < e->num_players; p++) {
+      ora_serializer_mask(e, p, scratch);
+      uint8_t* o = bits + ((size_t)i * (size_t)b->max_p + (size_t)p) * (size_t)b->mask_bytes;
+      for (int k = 0; k < n4; k++) if (scratch[k]) o[k >> 3] |= (uint8_t)(1u << (k & 7));
+    }
+  }
+  free(scratch);
   return 0;
 }
 

@@ -143,6 +143,23 @@ typedef struct ora_state_view {
 int32_t    ora_batch_read_state(ora_batch* b, int32_t env_begin, int32_t n, const ora_state_view* v);
 int32_t    ora_batch_write_state(ora_batch* b, int32_t env_begin, int32_t n, const ora_state_view* v);
 
+/* ---- internal/experience: serializer + rewards ---- */
+/* GameState.Clone (state.go:37-70) */
+ora_engine* ora_engine_clone(const ora_engine* e);
+/* Serializer.StateToTensor (internal/experience/serializer.go:37-109): out[9*w*h], index c*h*w + y*w + x */
+void       ora_state_to_tensor(const ora_engine* e, int32_t player, float* out);
+/* Serializer.GenerateActionMask (serializer.go:112-176): mask[w*h*4], d = 0 up, 1 down, 2 left, 3 right */
+void       ora_serializer_mask(const ora_engine* e, int32_t player, uint8_t* mask);
+/* CalculateReward (internal/experience/rewards.go:40-85) with DefaultRewardConfig (:23-37) */
+float      ora_calculate_reward(const ora_engine* prev, const ora_engine* cur, int32_t player);
+float      ora_army_advantage(const ora_engine* e, int32_t player);               /* rewards.go:153-175 */
+void       ora_city_changes(const ora_engine* prev, const ora_engine* cur, int32_t player, int32_t* gained, int32_t* lost); /* :110-129 */
+/* batch forms: begin = TurnProcessor.captureStateForExperience (turn_processor.go:116-121) */
+int32_t    ora_batch_experience_begin(ora_batch* b);
+int32_t    ora_batch_rewards(ora_batch* b, float* rewards /*[B][max_p]*/, uint8_t* done /*[B] or NULL*/);
+int32_t    ora_batch_observe(ora_batch* b, int32_t player, float* out /*[B][9*stride]*/);
+int32_t    ora_batch_serializer_mask(ora_batch* b, uint8_t* bits /*[B][max_p][mask_bytes]*/);
+
 /* ---- synthetic inputs (the build's own spec; no reference counterpart
  * is reproducible here because Go math/rand is absent) ---- */
 uint32_t   ora_fmix32(uint32_t h);

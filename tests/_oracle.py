@@ -131,6 +131,19 @@ def lib():
     L.ora_batch_set_pool.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, i32p, i32p, i32p]
     L.ora_batch_rollout.restype = C.c_int64
     L.ora_batch_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
+    L.ora_engine_clone.restype = C.c_void_p
+    L.ora_engine_clone.argtypes = [C.c_void_p]
+    L.ora_state_to_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
+    L.ora_serializer_mask.argtypes = [C.c_void_p, C.c_int32, u8p]
+    L.ora_calculate_reward.restype = C.c_float
+    L.ora_calculate_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.ora_army_advantage.restype = C.c_float
+    L.ora_army_advantage.argtypes = [C.c_void_p, C.c_int32]
+    L.ora_city_changes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, i32p, i32p]
+    L.ora_batch_experience_begin.argtypes = [C.c_void_p]
+    L.ora_batch_rewards.argtypes = [C.c_void_p, C.POINTER(C.c_float), u8p]
+    L.ora_batch_observe.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
+    L.ora_batch_serializer_mask.argtypes = [C.c_void_p, u8p]
     _LIB = L
     return L
 
@@ -210,6 +223,16 @@ class OracleEngine:
         f = np.zeros(self.w * self.h, np.uint8)
         self.L.ora_engine_player_visibility(self.e, player, _ptr(v, u8p), _ptr(f, u8p))
         return v, f
+
+    def state_to_tensor(self, player):
+        out = np.zeros(9 * self.w * self.h, np.float32)
+        self.L.ora_state_to_tensor(self.e, player, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def serializer_mask(self, player):
+        m = np.zeros(self.w * self.h * 4, np.uint8)
+        self.L.ora_serializer_mask(self.e, player, _ptr(m, u8p))
+        return m
 
     def owned(self, p):
         n = self.L.ora_player_num_owned(self.e, p)
@@ -318,6 +341,26 @@ class OracleBatch:
         v = make_view(StateView, arrays)
         rc = self.L.ora_batch_write_state(self.b, env_begin, n, C.byref(v))
         assert rc == 0, rc
+
+    def experience_begin(self):
+        self.L.ora_batch_experience_begin(self.b)
+
+    def rewards(self):
+        r = np.zeros((self.B, self.max_p), np.float32)
+        d = np.zeros(self.B, np.uint8)
+        rc = self.L.ora_batch_rewards(self.b, r.ctypes.data_as(C.POINTER(C.c_float)), _ptr(d, u8p))
+        assert rc == 0
+        return r, d
+
+    def observe(self, player):
+        out = np.zeros((self.B, 9 * self.stride), np.float32)
+        self.L.ora_batch_observe(self.b, player, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def serializer_mask(self):
+        bits = np.zeros((self.B, self.max_p, self.mask_bytes), np.uint8)
+        self.L.ora_batch_serializer_mask(self.b, _ptr(bits, u8p))
+        return bits
 
     def set_pool(self, pool_size, seed, w=None, h=None, p=None):
         cv = lambda a: None if a is None else np.ascontiguousarray(a, np.int32)

@@ -1,0 +1,140 @@
+"""GPU parity of the internal/experience side channel: observation tensors,
+serializer masks and rewards from the HIP path vs the CPU oracle.  float32 values must be
+bit-identical: same operation order, no fused multiply-add (tolerance 0)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _harness as H
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_kats.json")) as f:
+    CASES = json.load(f)["cases"]
+
+
+def by_kind(kind):
+    return [pytest.param(c, id=c["name"]) for c in CASES if c["kind"] == kind]
+
+
+@pytest.fixture(scope="module")
+def g():
+    import generalsreinforcementlearning_amd as g
+    g.load()
+    return g
+
+
+def _hand_built(g, c, tiles, fog=False, visible=None):
+    """createTestGameState-style state on the HIP engine: reset, then poke Turn 1 / alive / visibility."""
+    w, h, P = c["w"], c["h"], c.get("players", 2)
+    eng = g.VecEngine(1, w, h, P, fog_of_war=fog)
+    army, owner, typ = O.planes_from_tiles(w, h, tiles)
+    eng.reset(army[None], owner[None], typ[None])
+    upd = {"turn": np.array([1], np.int32), "alive": np.ones((1, P), np.uint8), "done": np.zeros(1, np.uint8)}
+    if visible is not None:
+        upd["visible"] = visible[None]
+    eng.write_state(upd)
+    return eng
+
+
+def _visible_plane(c):
+    n = c["w"] * c["h"]
+    v = np.zeros(n, np.uint8)
+    if c.get("visible_all"):
+        v[:] = (1 << c.get("players", 2)) - 1
+    for p, tiles in c.get("visible_tiles", {}).items():
+        v[tiles] |= 1 << int(p)
+    return v
+
+
+@pytest.mark.parametrize("c", by_kind("tensor"))
+def test_golden_state_to_tensor(g, c):
+    from test_oracle_golden import f32_expr
+    eng = _hand_built(g, c, c["tiles"], fog=c["fog"], visible=_visible_plane(c))
+    out = eng.observe(c["player"])[0][: 9 * c["w"] * c["h"]]
+    for i, v in c["expect"]["values"]:
+        assert out[i] == f32_expr(v), (i, out[i], v)
+
+
+@pytest.mark.parametrize("c", by_kind("ser_mask"))
+def test_golden_serializer_mask(g, c):
+    eng = _hand_built(g, c, c["tiles"])
+    m = g.unpack_legal_bits(eng.serializer_mask_bits()[0, c["player"]], c["w"], c["h"])
+    assert len(m) == c["expect"]["size"]
+    assert all(m[i] for i in c["expect"]["true"]) and not any(m[i] for i in c["expect"]["false"])
+
+
+@pytest.mark.parametrize("c", by_kind("reward"))
+def test_golden_rewards(g, c):
+    """prev / cur are two hand-built states (rewards_test.go): snapshot prev, overwrite with cur."""
+    from test_oracle_golden import expected_reward, experience_engine
+    eng = _hand_built(g, c, c["prev"])
+    eng.experience_begin()
+    army, owner, typ = O.planes_from_tiles(c["w"], c["h"], c["cur"])
+    eng.write_state({"army": army[None], "owner": owner[None], "type": typ[None], "turn": np.array([2], np.int32)})
+    r, done = eng.experience_rewards()
+    prev, cur = experience_engine(c, c["prev"]), experience_engine(c, c["cur"], alive=c.get("alive_cur"))
+    exp = expected_reward(c, prev, cur)
+    assert not done[0]
+    assert r[0, c["player"]] == np.float32(O.lib().ora_calculate_reward(prev.e, cur.e, c["player"]))  # bit-exact vs oracle
+    assert abs(float(r[0, c["player"]]) - float(exp)) <= max(c["expect"]["delta"], 0), (r, exp)
+
+
+@pytest.mark.parametrize("name,B,pattern,fog", [("20x20_p4", 128, [(20, 20, 4)], True), ("mixed", 96, [(10, 10, 2), (15, 15, 3), (20, 20, 4)], True),
+                                               ("10x10_fog_off", 128, [(10, 10, 2)], False), ("tiny", 48, [(3, 3, 2), (5, 7, 3), (8, 8, 2)], True)],
+                         ids=lambda v: v if isinstance(v, str) else None)
+def test_experience_channel_matches_oracle(g, name, B, pattern, fog):
+    sizes = [pattern[i % len(pattern)] for i in range(B)]
+    mw, mh, mp = max(s[0] for s in sizes), max(s[1] for s in sizes), max(s[2] for s in sizes)
+    army, owner, typ, w, h, p = H.gen_boards(99, sizes, mw, mh)
+    eng = g.VecEngine(B, mw, mh, mp, fog_of_war=fog)
+    ora = O.OracleBatch(B, mw, mh, mp, fog=fog)
+    eng.reset(army, owner, typ, w, h, p)
+    ora.reset(army, owner, typ, w, h, p)
+    saw_terminal = False
+    for k in range(150):
+        acts = ora.agent_actions(5, 10)
+        eng.experience_begin()
+        ora.experience_begin()
+        assert np.array_equal(eng.step(acts), ora.step(acts))
+        hr, hd = eng.experience_rewards()
+        orr, od = ora.rewards()
+        assert np.array_equal(hr.view(np.uint32), orr.view(np.uint32)), f"{name} turn {k}: rewards differ {hr[hr != orr][:6]} vs {orr[hr != orr][:6]}"
+        assert np.array_equal(hd, od.astype(bool))
+        saw_terminal |= bool(od.any())
+        if k % 10 == 0:
+            assert np.array_equal(eng.serializer_mask_bits(), ora.serializer_mask())
+            for player in range(mp):
+                assert np.array_equal(eng.observe(player).view(np.uint32), ora.observe(player).view(np.uint32)), (name, k, player)
+            allp = eng.observe(-1)
+            assert np.array_equal(allp[:, 1].view(np.uint32), ora.observe(1).view(np.uint32))
+    assert np.abs(orr).sum() > 0
+    H.assert_states_equal(eng.game_state(), ora.read_state(), name)
+
+
+def test_rewards_at_game_end_and_after_redeal(g):
+    """Terminal +-1 (rewards.go:49-56) and the 'no predecessor' rule for re-dealt boards."""
+    B = 128
+    sizes = [(6, 6, 2)] * B
+    army, owner, typ, w, h, p = H.gen_boards(3, sizes, 6, 6)
+    eng = g.VecEngine(B, 6, 6, 2, auto_reset=True)
+    ora = O.OracleBatch(B, 6, 6, 2)
+    eng.reset(army, owner, typ, w, h, p)
+    ora.reset(army, owner, typ, w, h, p)
+    eng.build_board_pool(17, 4)
+    ora.set_pool(17, 4)
+    wins = 0
+    for k in range(400):
+        acts = ora.agent_actions(8)
+        eng.experience_begin()
+        ora.experience_begin()
+        assert np.array_equal(eng.step(acts), ora.step(acts))
+        hr, hd = eng.experience_rewards()
+        orr, od = ora.rewards()
+        assert np.array_equal(hr.view(np.uint32), orr.view(np.uint32)), k
+        wins += int((orr == 1.0).sum())
+    assert wins > 0, "no game finished: the terminal branch was not exercised"

@@ -190,3 +190,94 @@ def check_mask_expect(m, e):
         assert len(true_idx) > e["count_gt"]
     if "count_lt" in e:
         assert len(true_idx) < e["count_lt"]
+
+
+# ------------------------------------------------------------------ internal/experience vectors
+REWARD_CONFIG = {"WinGame": 1.0, "LoseGame": -1.0, "CaptureCity": 0.1, "LoseCity": -0.1, "CaptureGeneral": 0.5, "LoseGeneral": -0.5,
+                 "TerritoryGained": 0.01, "TerritoryLost": -0.01, "ArmyGained": 0.001, "ArmyLost": -0.001, "ArmyAdvantage": 0.05}
+
+
+def f32_expr(v):
+    """'a/b' -> float32(a)/float32(b) like the Go tests compute their expectations."""
+    if isinstance(v, str):
+        a, b = v.split("/")
+        return np.float32(np.float32(float(a)) / np.float32(float(b)))
+    return np.float32(v)
+
+
+def experience_engine(c, tiles, fog=False, alive=None):
+    """createTestGameState-style hand-built state: no init pass, Turn 1, both players alive."""
+    eng = O.OracleEngine(c["w"], c["h"], c.get("players", 2), tiles, fog=fog, setup=False)
+    eng.L.ora_engine_set_turn(eng.e, 1)
+    for p, v in (alive or {}).items():
+        eng.L.ora_player_set_alive(eng.e, int(p), int(v))
+    return eng
+
+
+def set_visibility(eng, c):
+    n = c["w"] * c["h"]
+    if c.get("visible_all"):
+        for t in range(n):
+            eng.tile(t % c["w"], t // c["w"]).visible = (1 << c.get("players", 2)) - 1
+    for p, tiles in c.get("visible_tiles", {}).items():
+        for t in tiles:
+            eng.tile(t % c["w"], t // c["w"]).visible |= 1 << int(p)
+
+
+@pytest.mark.parametrize("c", by_kind("tensor"))
+def test_state_to_tensor(c):
+    eng = experience_engine(c, c["tiles"], fog=c["fog"])
+    set_visibility(eng, c)
+    out = eng.state_to_tensor(c["player"])
+    e = c["expect"]
+    if "size" in e:
+        assert len(out) == e["size"]
+    for i, v in e["values"]:
+        assert out[i] == f32_expr(v), (i, out[i], v)
+
+
+@pytest.mark.parametrize("c", by_kind("ser_mask"))
+def test_serializer_mask(c):
+    eng = experience_engine(c, c["tiles"])
+    m = eng.serializer_mask(c["player"])
+    assert len(m) == c["expect"]["size"]
+    assert all(m[i] for i in c["expect"]["true"]) and not any(m[i] for i in c["expect"]["false"])
+
+
+def expected_reward(c, prev, cur):
+    L = O.lib()
+    total = np.float32(0)
+    for name, mult in c["expect"]["terms"]:
+        if name == "ArmyAdvantageCur":
+            total += np.float32(L.ora_army_advantage(cur.e, c["player"])) * np.float32(REWARD_CONFIG["ArmyAdvantage"])
+        elif name == "ArmyAdvantageDelta":
+            total += (np.float32(L.ora_army_advantage(cur.e, c["player"])) - np.float32(L.ora_army_advantage(prev.e, c["player"]))) * np.float32(REWARD_CONFIG["ArmyAdvantage"])
+        else:
+            total += np.float32(mult) * np.float32(REWARD_CONFIG[name])
+    return total
+
+
+@pytest.mark.parametrize("c", by_kind("reward"))
+def test_calculate_reward(c):
+    prev, cur = experience_engine(c, c["prev"]), experience_engine(c, c["cur"], alive=c.get("alive_cur"))
+    r = np.float32(O.lib().ora_calculate_reward(prev.e, cur.e, c["player"]))
+    exp = expected_reward(c, prev, cur)
+    if c["expect"]["delta"] == 0:
+        assert r == exp, (r, exp)
+    else:
+        assert abs(float(r) - float(exp)) <= c["expect"]["delta"], (r, exp)
+
+
+@pytest.mark.parametrize("c", by_kind("army_advantage"))
+def test_army_advantage(c):
+    eng = experience_engine(c, c["tiles"])
+    for p in ("0", "1"):
+        assert abs(float(O.lib().ora_army_advantage(eng.e, int(p))) - float(f32_expr(c["expect"][p]))) <= c["expect"]["delta"]
+
+
+@pytest.mark.parametrize("c", by_kind("city_changes"))
+def test_city_changes(c):
+    prev, cur = experience_engine(c, c["prev"]), experience_engine(c, c["cur"])
+    g, l = C.c_int32(), C.c_int32()
+    O.lib().ora_city_changes(prev.e, cur.e, c["player"], C.byref(g), C.byref(l))
+    assert (g.value, l.value) == (c["expect"]["gained"], c["expect"]["lost"])
