@@ -443,7 +443,12 @@ int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err, uint
     a.actions = actions;
     a.err = err;
   }
-  if (legal_bits) a.flags |= KF_EMIT;
+  if (legal_bits) {
+    // envs that sit the call out (GVEC_ACT_SKIP_ENV) or are frozen write no masks: the buffer must
+    // already describe them
+    if (!h->legal_valid) RET_IF(refresh_legal(h));
+    a.flags |= KF_EMIT | KF_LMVALID;
+  }
   HIPCHK(launch_step(h->var, a, h->stream));
   h->legal_valid = legal_bits != nullptr;
   if (mem == GVEC_MEM_HOST) {

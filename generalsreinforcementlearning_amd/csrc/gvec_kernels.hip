@@ -149,6 +149,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
+  if constexpr (!AGENT) {
+    // GVEC_ACT_SKIP_ENV on player 0's action: this env sits the call out (nothing is read or
+    // written; the host keeps the legal-mask buffer current for such calls)
+    const uint32_t f0 = (uint32_t)uni((int)reinterpret_cast<const uint32_t*>(A.actions)[((size_t)env * A.pstride) * 2 + 1]);
+    if (f0 & GVEC_ACT_SKIP_ENV) {
+      if (A.err && lane == 0) A.err[env] = 0;
+      return;
+    }
+  }
   B b;
   uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
   const size_t army_dw = (size_t)NSLOT * 64;

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import Config, GvecError, RolloutStats, StateView, check
 
 TILE_NORMAL, TILE_GENERAL, TILE_CITY, TILE_MOUNTAIN = 0, 1, 2, 3  # core/board.go:20-26
-ACT_VALID, ACT_HALF = 1, 2
+ACT_VALID, ACT_HALF, ACT_SKIP_ENV = 1, 2, 4
 ERR_NAMES = {0: None, 1: "ErrInvalidCoordinates", 2: "ErrNotAdjacent", 3: "ErrNotOwned", 4: "ErrInsufficientArmy",
              5: "ErrGameOver", 6: "ErrInvalidPlayer", 7: "ErrMoveToSelf", 8: "ErrTargetIsMountain"}  # core/errors.go:8-17
 

@@ -79,6 +79,11 @@ extern "C" {
  * The slot index in actions[env][player] is MoveAction.PlayerID. */
 #define GVEC_ACT_VALID 1u   /* 0 = nil action (no-op this turn)                        */
 #define GVEC_ACT_HALF  2u   /* proto Action.half; MoveAll = !half                      */
+#define GVEC_ACT_SKIP_ENV 4u /* on actions[env][0] only: this env does not play a turn in
+                               this call (err 0, state untouched).  Lets a vector env
+                               mirror clients whose games advance at different times
+                               (python/generals_gym/generals_env.py:226-241 returns
+                               before submitting anything on an invalid action).         */
 typedef struct gvec_action {
   int8_t  from_x, from_y, to_x, to_y;
   uint8_t flags;

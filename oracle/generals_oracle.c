@@ -590,7 +590,8 @@ int32_t ora_batch_step(ora_batch* b, const ora_action8* actions, int32_t* err, u
   for (int id = 0; id < b->num_envs; id++) {
     if (!b->env[id]) { if (err) err[id] = -1; continue; }
     int32_t rc;
-    if (b->pool_size > 0 && b->env[id]->game_over) { redeal_env(b, id); rc = 0; }
+    if (actions[(size_t)id * (size_t)b->max_p].flags & 4u) rc = 0;   /* GVEC_ACT_SKIP_ENV: sits this call out */
+    else if (b->pool_size > 0 && b->env[id]->game_over) { redeal_env(b, id); rc = 0; }
     else rc = step_env(b, id, actions + (size_t)id * (size_t)b->max_p);
     if (err) err[id] = rc;
     if (legal_bits) {

@@ -1,0 +1,251 @@
+"""The drop-in vector env against a scalar, line-by-line restatement of the
+reference's python/generals_gym/generals_env.py helpers and the server's proto fog rules
+(internal/grpc/gameserver/server.go:526-582).  The reference env itself cannot run here (needs
+gymnasium and a live Go server), so the restatement below is the checker; states come from the
+CPU oracle (CPU tests) and from the HIP engine (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+
+import _harness as H
+import _oracle as O
+from generalsreinforcementlearning_amd import vector_env as V
+
+DIRS = [(0, -1), (1, 0), (0, 1), (-1, 0)]
+
+
+class Tile:  # gamev1.Tile as the gym env reads it
+    def __init__(self, type_, owner_id, army_count, visible):
+        self.type, self.owner_id, self.army_count, self.visible = type_, owner_id, army_count, visible
+
+
+def ref_proto_tiles(owner, army, typ, vis, fog):
+    """server.go:556-582, one env."""
+    out = []
+    for i in range(len(owner)):
+        t = Tile(int(typ[i]), int(owner[i]), int(army[i]), bool(vis[i]))
+        fow = bool(fog[i])
+        if not t.visible and not fow:
+            t.type, t.owner_id, t.army_count = 0, -1, 0
+        elif fow and not t.visible:
+            t.owner_id, t.army_count = -1, 0
+        out.append(t)
+    return out
+
+
+def ref_get_observation(tiles, w, h, player_id, turn_count, max_turns):
+    """generals_env.py:291-342"""
+    obs = np.zeros((9, h, w), dtype=np.float32)
+    for y in range(h):
+        for x in range(w):
+            tile = tiles[y * w + x]
+            if tile.visible:
+                obs[0, y, x] = 1.0
+            if tile.owner_id == player_id:
+                obs[1, y, x] = 0.5
+            elif tile.owner_id >= 0:
+                obs[1, y, x] = 1.0
+            else:
+                obs[1, y, x] = 0.0
+            if tile.army_count > 0:
+                obs[2, y, x] = np.log(tile.army_count + 1) / 10.0
+            if tile.type == 0:
+                obs[3, y, x] = 1.0
+            elif tile.type == 3:
+                obs[4, y, x] = 1.0
+            elif tile.type == 2:
+                obs[5, y, x] = 1.0
+            elif tile.type == 1:
+                obs[6, y, x] = 1.0
+    obs[7, :, :] = min(turn_count / max_turns, 1.0)
+    return obs
+
+
+def ref_valid_mask(tiles, w, h, player_id):
+    """generals_env.py:344-387"""
+    mask = np.zeros(w * h * 5, dtype=bool)
+    for y in range(h):
+        for x in range(w):
+            idx = y * w + x
+            tile = tiles[idx]
+            if tile.owner_id != player_id or tile.army_count <= 1:
+                continue
+            for direction, (dx, dy) in enumerate(DIRS):
+                nx, ny = x + dx, y + dy
+                if 0 <= nx < w and 0 <= ny < h:
+                    if tiles[ny * w + nx].type != 3:
+                        mask[idx * 5 + direction] = True
+                        mask[idx * 5 + 4] = True
+    return mask
+
+
+def ref_decode(action_idx, w, h):
+    """generals_env.py:402-425"""
+    from_idx, move_info = action_idx // 5, action_idx % 5
+    from_x, from_y = from_idx % w, from_idx // w
+    is_half = bool(move_info == 4)
+    if move_info < 4:
+        dx, dy = DIRS[move_info]
+        to_x, to_y = from_x + dx, from_y + dy
+    else:
+        for dx, dy in DIRS:
+            to_x, to_y = from_x + dx, from_y + dy
+            if 0 <= to_x < w and 0 <= to_y < h:
+                break
+    return from_x, from_y, to_x, to_y, is_half
+
+
+def ref_reward(prev, cur, e, player_id):
+    """generals_env.py:499-561 on PlayerState fields (server.go:526-553)."""
+    if cur["done"][e]:
+        return 100.0 if cur["winner"][e] == player_id else -100.0
+    reward = 0.0
+    reward += (int(cur["tile_count"][e, player_id]) - int(prev["tile_count"][e, player_id])) * 1.0
+    reward += (int(cur["army_count"][e, player_id]) - int(prev["army_count"][e, player_id])) * 0.01
+    for q in range(cur["alive"].shape[1]):
+        if q != player_id and prev["alive"][e, q] and not cur["alive"][e, q]:
+            reward += 50.0
+    return reward
+
+
+def _views(ora, B, w, h, player):
+    st = ora.read_state()
+    vis = np.zeros((B, w * h), np.uint8)
+    fog = np.zeros((B, w * h), np.uint8)
+    for e in range(B):
+        v, f = ora.engine(e).player_visibility(player)
+        vis[e], fog[e] = v, f
+    return st, vis, fog
+
+
+def test_pure_functions_match_scalar_restatement():
+    B, w, h, P = 24, 9, 7, 3
+    sizes = [(w, h, P)] * B
+    army, owner, typ, ws, hs, ps = H.gen_boards(5, sizes, w, h)
+    ora = O.OracleBatch(B, w, h, P)
+    ora.reset(army, owner, typ, ws, hs, ps)
+    prev = None
+    for k in range(80):
+        ora.step(ora.agent_actions(3, 5))
+        if k % 8 != 0:
+            continue
+        st, vis, fog = _views(ora, B, w, h, 0)
+        view = V.proto_view(st["owner"], st["army"], st["type"], vis, fog)
+        tc = np.full(B, k + 1)
+        obs = V.build_observation(view, 0, tc, 50, w, h)
+        mask = V.valid_actions_mask(view, 0, w, h)
+        for e in range(B):
+            tiles = ref_proto_tiles(st["owner"][e], st["army"][e], st["type"][e], vis[e], fog[e])
+            assert np.array_equal(obs[e], ref_get_observation(tiles, w, h, 0, k + 1, 50)), (k, e)
+            assert np.array_equal(mask[e], ref_valid_mask(tiles, w, h, 0)), (k, e)
+        stats = {f: st[f] for f in ("done", "winner", "alive", "army_count", "tile_count")}
+        if prev is not None:
+            r = V.calculate_reward(prev, stats, 0)
+            for e in range(B):
+                assert r[e] == ref_reward(prev, stats, e, 0), (k, e)
+        prev = stats
+    assert obs.dtype == np.float32 and obs.shape == (B, 9, h, w) and mask.shape == (B, w * h * 5)
+
+
+def test_decode_actions_matches_reference_quirk():
+    w, h = 6, 4
+    acts = np.arange(w * h * 5)
+    fx, fy, tx, ty, half, d = V.decode_actions(acts, w, h)
+    for a in acts:
+        assert (fx[a], fy[a], tx[a], ty[a], bool(half[a])) == ref_decode(int(a), w, h), a
+
+
+class OracleBackedEngine:
+    """The VecEngine surface GeneralsVecEnv uses, served by the CPU oracle (same plane formats)."""
+
+    def __init__(self, num_envs, width, height, players, fog_of_war=True, device=0, auto_reset=False):
+        self.B, self.w, self.h, self.p = num_envs, width, height, players
+        self.ora = O.OracleBatch(num_envs, width, height, players, fog=fog_of_war)
+
+    def reset_generated(self, seed):
+        army, owner, typ, ws, hs, ps = H.gen_boards(seed, [(self.w, self.h, self.p)] * self.B, self.w, self.h)
+        self.ora.reset(army, owner, typ, ws, hs, ps)
+
+    def build_board_pool(self, n, seed):
+        self.ora.set_pool(n, seed)
+
+    def game_state(self, fields=None):
+        return self.ora.read_state(fields=fields)
+
+    def write_state(self, arrays):
+        self.ora.write_state(arrays)
+
+    def compute_player_visibility(self, player):
+        vis = np.zeros((self.B, self.w * self.h), bool)
+        fog = np.zeros((self.B, self.w * self.h), bool)
+        for e in range(self.B):
+            v, f = self.ora.engine(e).player_visibility(player)
+            vis[e], fog[e] = v, f
+        return vis, fog
+
+    def agent_actions(self, seed):
+        return self.ora.agent_actions(seed)
+
+    def step(self, acts):
+        return self.ora.step(acts)
+
+    def close(self):
+        pass
+
+
+def _episode_flow(env):
+    assert env.single_observation_shape == (9, 8, 8) and env.single_action_n == 8 * 8 * 5
+    obs, info = env.reset()
+    assert obs.shape == (64, 9, 8, 8) and obs.dtype == np.float32 and obs.min() >= 0.0 and obs.max() <= 1.0
+    assert info["valid_actions_mask"].shape == (64, 320) and info["valid_actions_mask"].any(1).all()
+    rng = np.random.default_rng(0)
+    seen = {"invalid": 0, "terminated": 0, "truncated": 0, "reset": 0}
+    total_reward = np.zeros(64)
+    for k in range(130):
+        mask = info["valid_actions_mask"]
+        acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in mask])
+        if k % 7 == 3:
+            acts[:4] = [int(np.flatnonzero(~m)[0]) for m in mask[:4]]  # deliberately invalid
+        turn_before = info["turn"].copy()
+        obs, reward, terminated, truncated, info = env.step(acts)
+        inval = info["invalid_action"]
+        if k % 7 == 3:
+            assert (inval[:4] | info["reset"][:4]).all() and (reward[:4][~info["reset"][:4]] == -0.1).all()
+            assert (info["turn"][:4][~info["reset"][:4]] == turn_before[:4][~info["reset"][:4]]).all()  # game did not advance
+        seen["invalid"] += int(inval.sum())
+        seen["terminated"] += int(terminated.sum())
+        seen["truncated"] += int(truncated.sum())
+        seen["reset"] += int(info["reset"].sum())
+        assert (reward[terminated] != 0).all() and set(np.unique(np.abs(reward[terminated]))) <= {100.0}
+        assert (info["turn"][info["reset"]] == 0).all()
+        total_reward += reward
+    assert seen["invalid"] > 0 and seen["truncated"] + seen["terminated"] > 0 and seen["reset"] > 0
+    env.close()
+
+
+def test_vector_env_episode_flow_on_oracle_engine(monkeypatch):
+    monkeypatch.setattr(V, "VecEngine", OracleBackedEngine)
+    _episode_flow(V.GeneralsVecEnv(64, board_width=8, board_height=8, max_players=2, max_turns=40, seed=3))
+
+
+@pytest.mark.gpu
+def test_vector_env_api_and_episode_flow():
+    _episode_flow(V.GeneralsVecEnv(64, board_width=8, board_height=8, max_players=2, max_turns=40, seed=3))
+
+
+@pytest.mark.gpu
+def test_vector_env_matches_scalar_restatement_on_hip_states():
+    env = V.GeneralsVecEnv(32, board_width=10, board_height=10, max_players=2, max_turns=100, seed=9)
+    obs, info = env.reset()
+    rng = np.random.default_rng(1)
+    for k in range(40):
+        acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in info["valid_actions_mask"]])
+        obs, reward, terminated, truncated, info = env.step(acts)
+        st = env.engine.game_state()
+        vis, fog = env.engine.compute_player_visibility(0)
+        for e in range(0, 32, 5):
+            tiles = ref_proto_tiles(st["owner"][e], st["army"][e], st["type"][e], vis[e], fog[e])
+            assert np.array_equal(obs[e], ref_get_observation(tiles, 10, 10, 0, int(info["turn"][e]), 100))
+            assert np.array_equal(info["valid_actions_mask"][e], ref_valid_mask(tiles, 10, 10, 0))
+    env.close()
