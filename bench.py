@@ -68,6 +68,61 @@ def cpu_baseline(w, h, p, fog, seed, budget_s=12.0):
             "note": "C restatement of the Go engine (oracle/generals_oracle.c); the Go toolchain is absent on this host"}
 
 
+class _NullEngine:
+    """Stands in for VecEngine in --rehearse-cpu: same calls, no work (there is no CPU engine)."""
+
+    def __init__(self, rec_bytes):
+        self.rec = rec_bytes
+
+    def rollout(self, *a, **k):
+        return None
+
+    def state_bytes_per_env(self):
+        return self.rec
+
+    def export_records(self, ptr, lo, n):
+        return None
+
+
+def rehearse_cpu(args):
+    """The N > 1 choreography of main() on CPU tensors with the gloo backend: rendezvous from the
+    torchrun environment, per-step record gather to rank 0, barrier-bracketed timing, MAX over ranks,
+    one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from generalsreinforcementlearning_amd.sharding import RecordGather
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    B = args.envs_per_gpu
+    eng = _NullEngine(64)
+    ge = min(args.gather_envs, B)
+    rg = RecordGather(ge * eng.state_bytes_per_env(), torch.device("cpu"), dst=0) if ge > 0 else None
+    got = 0
+    for k in range(args.warmup):
+        eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
+        if rg is not None:
+            rg.send.fill_((rank * 31 + k) % 251)
+            out = rg.gather()
+            if rank == 0:
+                assert all(int(out[r][0]) == (r * 31 + k) % 251 for r in range(world))
+                got += 1
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathers": got,
+                          "value": world * B * args.steps / float(t.item()), "scaling": "weak"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,9 +139,14 @@ def main():
                     help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="control-flow rehearsal of the multi-rank path on CPU (gloo, no GPU, no engine work): "
+                         "used by tests/test_bench_distributed.py; prints a line marked \"rehearsal\": true, never a result")
     args = ap.parse_args()
 
     import torch
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     import generalsreinforcementlearning_amd as g
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
