@@ -253,7 +253,7 @@ def main():
                        "envs_per_gpu": B, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
                        "gather_envs_per_step": (args.gather_envs if n > 1 else 0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "gvec::step_kernel<4,7>", "algorithmic_bytes_per_env_step": abytes,
+                         "traffic": traffic, "kernel": "gvec::step_kernel<4,7,true>", "algorithmic_bytes_per_env_step": abytes,
                          "units_per_launch": B, "kernel_ms": kernel_ms},
         }
         if fused:

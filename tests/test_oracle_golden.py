@@ -281,3 +281,12 @@ def test_city_changes(c):
     g, l = C.c_int32(), C.c_int32()
     O.lib().ora_city_changes(prev.e, cur.e, c["player"], C.byref(g), C.byref(l))
     assert (g.value, l.value) == (c["expect"]["gained"], c["expect"]["lost"])
+
+
+def test_oracle_is_clean_under_sanitizers():
+    """address/UB sanitizers on the CPU build (GPU ASan is not available on this pool)."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "-s", "sanitize"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitizer run OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
