@@ -221,26 +221,32 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rollout_kernel(StepArgs 
   bool types_dirty = false;
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
-  for (int k = 0;; ++k) {
-    b.template legal_masks<false>(lm);  // the masks of the CURRENT state: input of the agent, output after the last turn
+  const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
+  int k = 0;
+  // The hot inner loop plays turns while the game is live; the rare events (game over: re-deal from
+  // the pool, or freeze) sit in the outer loop so they do not shape the inner loop's registers.
+  for (;;) {
+    b.template legal_masks<false>(lm);  // the masks of the CURRENT state: the agent's input, the output at the end
+    while (k < A.turns && !(b.hflags & HF_DONE)) {
+      uint32_t alo, ahi;
+      agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+      bool aborted;
+      err = b.turn_step(alo, ahi, A, aborted);
+      n_steps += 1u;
+      n_abort += aborted ? 1u : 0u;
+      n_done += (b.hflags & HF_DONE) ? 1u : 0u;
+      ++k;
+      b.template legal_masks<false>(lm);
+    }
     if (k >= A.turns) break;
-    if (b.hflags & HF_DONE) {
-      if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
-        redeal<MAXP, NSLOT>(b, A, env, lds);
-        types_dirty = true;
-        err = 0u;
-        continue;
-      }
+    if (!can_redeal) {
       err = GVEC_ERR_GAME_OVER;  // frozen for the rest of the launch
       break;
     }
-    uint32_t alo, ahi;
-    agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
-    bool aborted;
-    err = b.turn_step(alo, ahi, A, aborted);
-    n_steps += 1u;
-    n_abort += aborted ? 1u : 0u;
-    n_done += (b.hflags & HF_DONE) ? 1u : 0u;
+    redeal<MAXP, NSLOT>(b, A, env, lds);  // this turn slot is spent re-dealing (vector-env auto-reset)
+    types_dirty = true;
+    err = 0u;
+    ++k;
   }
   b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + n_steps);
   b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + n_abort);
