@@ -202,10 +202,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   }
 }
 
+// Waves per SIMD to ask of the register allocator for the fused rollout kernel.  With no HBM traffic
+// inside the turn loop the kernel is latency / issue bound, and occupancy pays even at the price of
+// a few scratch spills (measured on <4,7>, one-process A/B: default 4 waves 851 M env-steps/s,
+// 5: 934 M, 6: 1,014 M, 7: 1,043 M, 8: 1,050 M).  The bound scales with the board state the variant
+// must hold: planes + army slots + mask words + ~36 working registers.
+constexpr int rollout_waves(int maxp, int nslot) {
+  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + 36;
+  const int alloc = (need + 7) / 8 * 8;
+  const int w = 512 / alloc;
+  return w > 8 ? 8 : (w < 2 ? 2 : w);
+}
+
 // `turns` engine turns per launch with the board kept in registers / LDS (fused rollouts; always
 // with the on-device agent)
 template <int MAXP, int NSLOT>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rollout_kernel(StepArgs A) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
