@@ -171,25 +171,29 @@ def main():
     eng.build_board_pool(args.pool, args.seed * 7919 + rank)
     seed = args.seed
 
-    rg = None
-    side = None
+    rgs, side, slab_free = None, None, None
     if dist is not None and args.gather_envs > 0:
-        # the one real exchange step of the path: compact experience/state slabs -> rank 0 (StreamAggregator side)
+        # the one real exchange step of the path: compact experience/state slabs -> rank 0 (StreamAggregator side).
+        # Two slabs alternate so step k+1's export never waits for step k's gather on the side stream.
         from generalsreinforcementlearning_amd.sharding import RecordGather
         ge = min(args.gather_envs, B)
-        rg = RecordGather(ge * eng.state_bytes_per_env(), dev, dst=0)
+        rgs = [RecordGather(ge * eng.state_bytes_per_env(), dev, dst=0) for _ in range(2)]
+        slab_free = [None, None]
         side = torch.cuda.Stream()
 
     def one_step(k):
         eng.rollout(1, seed, 0, fused=False, want_stats=False)
-        if rg is not None:
+        if rgs is not None:
+            i = k & 1
             ge = min(args.gather_envs, B)
             lo = (k * ge) % max(1, B - ge + 1)
-            eng.export_records(rg.send.data_ptr(), lo, ge)  # on the compute stream, after this step's kernel
+            if slab_free[i] is not None:
+                stream.wait_event(slab_free[i])                  # slab i was last read by the gather of step k-2
+            eng.export_records(rgs[i].send.data_ptr(), lo, ge)   # on the compute stream, after this step's kernel
             side.wait_stream(stream)
             with torch.cuda.stream(side):
-                rg.gather()                                   # RCCL gather, overlapped with the next step
-            stream.wait_stream(side)                          # the send slab is reused next step
+                rgs[i].gather()                                   # RCCL gather over xGMI, overlapped with the next step
+                slab_free[i] = side.record_event()
 
     def sync_all():
         torch.cuda.synchronize()
