@@ -33,7 +33,7 @@ def algorithmic_bytes(w, h, p, mask=True):
     return 16 * w * h + 4 * p + 12 * p + (p * ((4 * w * h + 7) // 8) if mask else 0) + 16
 
 
-def cpu_baseline(w, h, p, fog, seed, budget_s=12.0):
+def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
     """Times the CPU oracle (test infrastructure) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -51,7 +51,7 @@ def cpu_baseline(w, h, p, fog, seed, budget_s=12.0):
     t0 = time.perf_counter()
     s0 = ora.rollout(4, seed, 0, threads=cores)
     dt = max(time.perf_counter() - t0, 1e-6)
-    turns = int(max(8, min(4000, budget_s / (dt / 4))))
+    turns = int(max(8, min(20000, budget_s / (dt / 4))))
     t0 = time.perf_counter()
     steps = ora.rollout(turns, seed, 0, threads=cores)
     dt = time.perf_counter() - t0
