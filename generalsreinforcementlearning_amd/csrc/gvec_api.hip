@@ -257,7 +257,8 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
     set_err("no kernel variant for %d players / %d tiles", cfg->max_players, h->stride);
     return GVEC_E_INVALID;
   }
-  h->fd = (h->stride + 31) / 32;  // dwords per flat bit-plane
+  // dwords per flat bit-plane: 2*nslot-1 or 2*nslot, so that the step kernel can be compiled for it
+  h->fd = (h->stride <= 32 * (2 * h->var.nslot - 1)) ? 2 * h->var.nslot - 1 : 2 * h->var.nslot;
   h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 5) * h->fd, 4);
   h->army_dw = h->var.nslot * 64;
   h->mask_bytes = (int)round_up((size_t)(h->stride + 1) / 2, 16);

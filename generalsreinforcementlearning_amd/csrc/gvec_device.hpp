@@ -17,8 +17,8 @@
 //     A flat plane reaches the tile domain with one ds_bpermute (dword 2s + (l>>5)) and a
 //     bit-field extract at bit l&31: no per-tile coordinates are ever computed.
 //
-// Planes are staged HBM -> LDS -> registers with flat 16-byte coalesced accesses; armies are
-// loaded straight into registers, 256 B per wave instruction.  Integer / bit work only: no MFMA
+// Planes and armies are loaded straight into registers (plane p: lane i reads dword i; armies:
+// 256 B per wave instruction); the planes block of one env is a contiguous, 16-byte aligned run.  Integer / bit work only: no MFMA
 // anywhere (HBM-roofline kernel).
 //
 // Every routine cites the Go function it reproduces (paths relative to
@@ -230,59 +230,46 @@ struct Board {
     if (lane < HDR_DW) hdr_env[lane] = hv;
   }
 
-  // planes: HBM --(flat dwordx4)--> LDS --(ds_read_b32, lane = dword of the bit string)--> registers
-  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, uint32_t* lds, int fd, int row_dw) {
+  // planes: lane i holds dword i of each bit string.  Staging the block through LDS with dwordx4
+  // copies was measured 4 % slower (the LDS pipe is as busy as the VALU in this kernel).
+  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd) {
     const int lane = lane_id();
-    for (int c = lane; c * 4 < row_dw; c += 64) {
-      uint4 q = *reinterpret_cast<const uint4*>(rows_env + 4 * c);
-      *reinterpret_cast<uint4*>(lds + 4 * c) = q;
-    }
-    wave_lds_fence();
     const bool on = lane < fd;
-    const uint32_t* l = lds + (on ? lane : 0);
+    const uint32_t* g = rows_env + (on ? lane : 0);
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      uint32_t a = l[(PL::OWN + p) * fd], b = l[(PL::LST + p) * fd], c = l[(PL::VIS + p) * fd];
+      uint32_t a = g[(PL::OWN + p) * fd], b = g[(PL::LST + p) * fd], c = g[(PL::VIS + p) * fd];
       own[p] = on ? a : 0u;
       lst[p] = on ? b : 0u;
       vis[p] = on ? c : 0u;
     }
-    uint32_t a = l[PL::CHG * fd], b = l[PL::VCH * fd], c = l[PL::GEN * fd], d = l[PL::CITY * fd], e = l[PL::MTN * fd];
+    uint32_t a = g[PL::CHG * fd], b = g[PL::VCH * fd], c = g[PL::GEN * fd], d = g[PL::CITY * fd], e = g[PL::MTN * fd];
     chg = on ? a : 0u;
     vch = on ? b : 0u;
     gen = on ? c : 0u;
     city = on ? d : 0u;
     mtn = on ? e : 0u;
-    wave_lds_fence();
   }
 
-  __device__ __forceinline__ void store_planes(uint32_t* rows_env, uint32_t* lds, int fd, bool with_types) const {
+  // The type planes change only when the env is re-dealt (with_types).
+  __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
     const int lane = lane_id();
     if (lane < fd) {
-      uint32_t* l = lds + lane;
+      uint32_t* g = rows_env + lane;
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
-        l[(PL::OWN + p) * fd] = own[p];
-        l[(PL::LST + p) * fd] = lst[p];
-        l[(PL::VIS + p) * fd] = vis[p];
+        g[(PL::OWN + p) * fd] = own[p];
+        g[(PL::LST + p) * fd] = lst[p];
+        g[(PL::VIS + p) * fd] = vis[p];
       }
-      l[PL::CHG * fd] = chg;
-      l[PL::VCH * fd] = vch;
+      g[PL::CHG * fd] = chg;
+      g[PL::VCH * fd] = vch;
       if (with_types) {
-        l[PL::GEN * fd] = gen;
-        l[PL::CITY * fd] = city;
-        l[PL::MTN * fd] = mtn;
+        g[PL::GEN * fd] = gen;
+        g[PL::CITY * fd] = city;
       }
     }
-    wave_lds_fence();
-    const int ndw = (with_types ? PL::COUNT : PL::MUTABLE) * fd;
-    for (int c = lane; c * 4 < ndw; c += 64) {
-      // the tail chunk may cover the first dwords of the (unchanged) type planes or the block's
-      // padding: those were staged into LDS by load_planes, so identical bytes are written back.
-      uint4 q = *reinterpret_cast<const uint4*>(lds + 4 * c);
-      *reinterpret_cast<uint4*>(rows_env + 4 * c) = q;
-    }
-    wave_lds_fence();
+    if (with_types && lane < row_dw - PL::MTN * fd) rows_env[PL::MTN * fd + lane] = mtn;  // lanes >= fd hold 0: the padding
   }
 
   // whole 64-tile slots travel both ways (the padding beyond N holds zeros).  Trimming the store to

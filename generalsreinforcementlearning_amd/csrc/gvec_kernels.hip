@@ -83,30 +83,21 @@ __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
 // =========================================================================================
 template <int MAXP, int NSLOT>
 __device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t* hdr, const uint32_t* rows,
-                                           const int32_t* army, uint32_t* lds, int fd, int row_dw) {
+                                           const int32_t* army, int fd) {
   b.load_hdr(hdr);
   b.geometry();
   b.load_army(army);
-  b.load_planes(rows, lds, fd, row_dw);
-}
-
-// per-wave LDS: [row_dw] staging of the bit-planes, then [NSLOT*64] army shadow
-template <int NSLOT>
-__device__ __forceinline__ uint32_t* wave_lds(uint32_t* smem, int wave, int row_dw, int32_t** larmy) {
-  uint32_t* base = smem + (size_t)wave * (size_t)(row_dw + NSLOT * 64);
-  *larmy = reinterpret_cast<int32_t*>(base + row_dw);
-  return base;
+  b.load_planes(rows, fd);
 }
 
 // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
 template <int MAXP, int NSLOT>
-__device__ __forceinline__ void redeal(Board<MAXP, NSLOT>& b, const StepArgs& A, int env, uint32_t* lds) {
+__device__ __forceinline__ void redeal(Board<MAXP, NSLOT>& b, const StepArgs& A, int env, int fd, int row_dw) {
   const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
   const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
   const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
-  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * A.row_dw, A.pool_army + (size_t)j * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, A.pool_army + (size_t)j * NSLOT * 64, fd);
   b.hdr_set(H_EPISODE, episode);
   b.hdr_set(H_CNT_STEPS, cs);
   b.hdr_set(H_CNT_ABORT, ca);
@@ -141,9 +132,13 @@ __device__ __forceinline__ void store_masks(const Masks<MAXP, NSLOT>& lm, const 
 
 // ONE engine turn per launch, straight-line (gvec_step; per-turn rollouts).  AGENT: actions are
 // sampled on device from the legal-mask buffer, which the host guarantees to be current.
-template <int MAXP, int NSLOT, bool AGENT>
+// ODD: the planes are 2*NSLOT-1 dwords long (else 2*NSLOT): the plane stride is a compile-time
+// constant here, so every plane access is one instruction with an immediate offset.
+template <int MAXP, int NSLOT, bool AGENT, bool ODD>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
+  constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
+  __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];  // per wave: the action phase's army copy
   using B = Board<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -159,17 +154,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
     }
   }
   B b;
-  uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
+  b.larmy = army_shadow[wave];
   const size_t army_dw = (size_t)NSLOT * 64;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, A.army + (size_t)env * army_dw, FD);
   const bool emit = (A.flags & KF_EMIT) != 0u;
   uint32_t lm[MAXP][MPASS];
   uint32_t err = 0u;
   bool types_dirty = false, changed = true;
   if (b.hflags & HF_DONE) {
     if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
-      redeal<MAXP, NSLOT>(b, A, env, lds);
+      redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
       types_dirty = true;
     } else {
       err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
   }
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_army(A.army + (size_t)env * army_dw);
-  b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
+  b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
     b.template legal_masks<false>(lm);
@@ -205,10 +199,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) 
 // Waves per SIMD to ask of the register allocator for the fused rollout kernel.  With no HBM traffic
 // inside the turn loop the kernel is latency / issue bound, and occupancy pays even at the price of
 // a few scratch spills (measured on <4,7>, one-process A/B: default 4 waves 851 M env-steps/s,
-// 5: 934 M, 6: 1,014 M, 7: 1,043 M, 8: 1,050 M).  The bound scales with the board state the variant
-// must hold: planes + army slots + mask words + ~36 working registers.
+// 5: 934 M, 6: 1,024 M, 7: 1,056 M, 8: 990-1,050 M depending on where the spills land).  The bound
+// scales with the board state the variant must hold: planes + army slots + mask words + ~40
+// working registers.
 constexpr int rollout_waves(int maxp, int nslot) {
-  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + 36;
+  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + 40;
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
   return w > 8 ? 8 : (w < 2 ? 2 : w);
@@ -218,19 +213,17 @@ constexpr int rollout_waves(int maxp, int nslot) {
 // with the on-device agent)
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
   using B = Board<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
-  uint32_t* lds = wave_lds<NSLOT>(smem, wave, A.row_dw, &b.larmy);
+  b.larmy = army_shadow[wave];
   const size_t army_dw = (size_t)NSLOT * 64;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, A.fd);
   uint32_t lm[MAXP][MPASS];
-  bool types_dirty = false;
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
   const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
@@ -255,8 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
       err = GVEC_ERR_GAME_OVER;  // frozen for the rest of the launch
       break;
     }
-    redeal<MAXP, NSLOT>(b, A, env, lds);  // this turn slot is spent re-dealing (vector-env auto-reset)
-    types_dirty = true;
+    redeal<MAXP, NSLOT>(b, A, env, A.fd, A.row_dw);  // this turn slot is spent re-dealing (vector-env auto-reset)
     err = 0u;
     ++k;
   }
@@ -265,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + n_done);
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_army(A.army + (size_t)env * army_dw);
-  b.store_planes(A.rows + (size_t)env * A.row_dw, lds, A.fd, types_dirty);
+  b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   store_masks<MAXP, NSLOT>(lm, A, env);
 }
@@ -274,17 +266,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
 // MODE 0: Engine.GetLegalActionMask   1: random-agent actions   2: Serializer.GenerateActionMask
 template <int MAXP, int NSLOT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   uint32_t lm[MAXP][MPASS];
   if constexpr (MODE == 2) b.template legal_masks<true>(lm);
   else b.template legal_masks<false>(lm);
@@ -308,16 +297,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
 // =========================================================================================
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(ExperienceArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   uint32_t tail = 0u;  // lane p: territory, lane MAXP+p: armies, lane 2*MAXP: turn, +1: W|H<<8
 #pragma unroll
@@ -337,16 +323,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(Experien
 // compiled with -ffp-contract=off (Go on amd64 does not fuse multiply-add).
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(ExperienceArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[MAXP * A.fd + lane] : 0u;
   const int prev_turn = (int)rdlane(tail, 2 * MAXP);
@@ -397,16 +380,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(Experienc
 // player's perspective; the output is 9 coalesced channel planes per 64-tile slot.
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(ExperienceArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   const bool fog_on = (b.hflags & HF_FOG) != 0u;
   uint32_t own_any = 0u;
 #pragma unroll
@@ -454,13 +434,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
 // =========================================================================================
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
   const int env = A.env_ids ? uni(A.env_ids[i]) : A.dst_begin + i;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   uint32_t* hdr = A.hdr + (size_t)env * HDR_DW;
   uint32_t* rows = A.rows + (size_t)env * A.row_dw;
   int32_t* army = A.army + (size_t)env * NSLOT * 64;
@@ -490,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     for (int s = 0; s < NSLOT; ++s) b.army[s] = 0;
     b.geometry();
   } else {
-    load_board(b, hdr, rows, army, lds, A.fd, A.row_dw);
+    load_board(b, hdr, rows, army, A.fd);
   }
 
   // per-tile source planes are read coalesced in the tile domain (lane l, slot s = tile 64s+l);
@@ -582,7 +560,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   if (A.init) b.initial_setup();
   b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_army(army);
-  b.store_planes(rows, lds, A.fd, true);
+  b.store_planes(rows, A.fd, A.row_dw, true);
 }
 
 // =========================================================================================
@@ -590,17 +568,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
 // =========================================================================================
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
   const int env = A.env_begin + i;
-  uint32_t* lds = smem + (size_t)wave * (size_t)A.row_dw;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, lds, A.fd,
-             A.row_dw);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
   const uint32_t special = b.gen | b.city | b.mtn;
   uint32_t pv_plane = 0u;
@@ -867,78 +842,81 @@ static hipError_t dispatch(const Variant& v, F&& f) {
 }
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
-static inline size_t wave_lds(int row_dw) { return (size_t)WAVES_PER_BLOCK * (size_t)row_dw * sizeof(uint32_t); }
 
 hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
-    if (a.flags & KF_AGENT)
-      hipLaunchKernelGGL((step_kernel<P, S, true>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
-    else
-      hipLaunchKernelGGL((step_kernel<P, S, false>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
+    // the resident format keeps planes of 2*S-1 or 2*S dwords (gvec_api.hip: plane_dwords)
+    const bool odd = a.fd == 2 * S - 1, agent = (a.flags & KF_AGENT) != 0u;
+    if ((!odd && a.fd != 2 * S) || a.row_dw != (Planes<P>::COUNT * a.fd + 3) / 4 * 4) return hipErrorInvalidValue;
+    const dim3 grid = wave_grid(a.num_envs), block(64 * WAVES_PER_BLOCK);
+    if (agent && odd) hipLaunchKernelGGL((step_kernel<P, S, true, true>), grid, block, 0, s, a);
+    else if (agent) hipLaunchKernelGGL((step_kernel<P, S, true, false>), grid, block, 0, s, a);
+    else if (odd) hipLaunchKernelGGL((step_kernel<P, S, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<P, S, false, false>), grid, block, 0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
-    hipLaunchKernelGGL((rollout_kernel<P, S>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw + S * 64), s, a);
+    hipLaunchKernelGGL((rollout_kernel<P, S>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 1>), wave_grid(a.num_envs),
-                       dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
+                       dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_legal(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 0>), wave_grid(a.num_envs),
-                       dim3(64 * WAVES_PER_BLOCK), wave_lds(a.row_dw), s, a);
+                       dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_serializer_mask(const Variant& v, const StepArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 2>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((snapshot_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((rewards_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((observe_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((import_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
 hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((export_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
-                       wave_lds(a.row_dw), s, a);
+                       0, s, a);
     return hipGetLastError();
   });
 }
