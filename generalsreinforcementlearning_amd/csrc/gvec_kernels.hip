@@ -132,10 +132,22 @@ __device__ __forceinline__ void store_masks(const Masks<MAXP, NSLOT>& lm, const 
 
 // ONE engine turn per launch, straight-line (gvec_step; per-turn rollouts).  AGENT: actions are
 // sampled on device from the legal-mask buffer, which the host guarantees to be current.
+// Waves per SIMD asked of the register allocator: the board state a variant holds (planes, army
+// slots, mask words) plus ~32 working registers.  <4,7> fits 64 registers = 8 waves/SIMD without a
+// spill, which is worth 7 % over 7 waves (one-process A/B): the turn is a long dependent chain of
+// short cross-lane operations, and the VALU only stays fed with every wave slot occupied.
+constexpr int step_waves(int maxp, int nslot) {
+  const int state = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1);
+  const int need = state + (state + 32 <= 64 ? 32 : 40);  // larger variants: keep spills out of the turn
+  const int alloc = (need + 7) / 8 * 8;
+  const int w = 512 / alloc;
+  return w > 8 ? 8 : (w < 2 ? 2 : w);
+}
+
 // ODD: the planes are 2*NSLOT-1 dwords long (else 2*NSLOT): the plane stride is a compile-time
 // constant here, so every plane access is one instruction with an immediate offset.
 template <int MAXP, int NSLOT, bool AGENT, bool ODD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void step_kernel(StepArgs A) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void step_kernel(StepArgs A) {
   constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
   constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];  // per wave: the action phase's army copy
