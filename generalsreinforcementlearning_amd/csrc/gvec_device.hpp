@@ -349,6 +349,49 @@ struct Board {
     }
   }
 
+  // Wave-wide sums of MAXP per-lane accumulators in ONE reduction tree (a tree per player costs 6 DPP
+  // adds each).  First the accumulators are folded into one register, lane l keeping class
+  // l & (MAXP-1): at each level a lane keeps its own class's half and hands the other half to its
+  // partner (quad_perm / row_ror swaps).  Then lanes of equal class are summed: row_shr inside a row of
+  // 16, ds_swizzle (xor 16) and ds_bpermute (xor 32) across rows.  Returns a register whose lanes
+  // H_ARMYCNT+p hold the total of acc[p].
+  __device__ __forceinline__ uint32_t multi_sum(const int32_t (&acc)[MAXP]) const {
+    static_assert(MAXP == 2 || MAXP == 4 || MAXP == 8, "fold levels are written for 2, 4 or 8 players");
+    static_assert(H_ARMYCNT == 4, "the final row_shl assumes header lanes 4..4+MAXP-1");
+    const int lane = lane_id();
+    uint32_t m[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) m[p] = (uint32_t)acc[p];
+    {
+      const bool hi = (lane & 1) != 0;
+#pragma unroll
+      for (int i = 0; i < MAXP / 2; ++i) {
+        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
+        m[i] = keep + dpp0<0xB1>(give);  // quad_perm [1,0,3,2]
+      }
+    }
+    if constexpr (MAXP >= 4) {
+      const bool hi = (lane & 2) != 0;
+#pragma unroll
+      for (int i = 0; i < MAXP / 4; ++i) {
+        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
+        m[i] = keep + dpp0<0x4E>(give);  // quad_perm [2,3,0,1]
+      }
+    }
+    if constexpr (MAXP >= 8) {
+      const bool hi = (lane & 4) != 0;
+      const uint32_t keep = hi ? m[1] : m[0], give = hi ? m[0] : m[1];
+      m[0] = keep + dpp0<0x124>(give);  // row_ror:4 (the partner differs in bit 2; a bijection is all a sum needs)
+    }
+    uint32_t r = m[0];
+    if constexpr (MAXP <= 2) r += dpp0<0x112>(r);  // row_shr:2
+    if constexpr (MAXP <= 4) r += dpp0<0x114>(r);  // row_shr:4
+    r += dpp0<0x118>(r);                           // row_shr:8 -> the last MAXP lanes of each row hold the row's sums
+    r += (uint32_t)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);  // lane ^ 16
+    r += bperm((lane ^ 32) << 2, r);
+    return dpp0<0x100 + 12 - MAXP>(r);  // row_shl: lanes 16-MAXP.. of row 0 -> lanes 4..
+  }
+
   // ---- Engine.updatePlayerStats (stats.go:8-144) -------------------------------------------
   __device__ __forceinline__ void update_stats() {
     const int nc = (int)wave_sum(__builtin_popcount(chg));
@@ -364,10 +407,14 @@ struct Board {
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p], s);
     }
+    {  // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
+      const int lane = lane_id();
+      const uint32_t tot = multi_sum(acc);
+      hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
+    }
     alive = 0u;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      hdr_set(H_ARMYCNT + p, wave_sum((uint32_t)acc[p]));
       // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two
       // or more generals that order depends on Go map iteration.  Here: the highest tile index.
       const uint32_t g = lst[p] & gen;
