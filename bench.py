@@ -33,6 +33,14 @@ def algorithmic_bytes(w, h, p, mask=True):
     return 16 * w * h + 4 * p + 12 * p + (p * ((4 * w * h + 7) // 8) if mask else 0) + 16
 
 
+def step_kernel_name(w, h, p):
+    """The step_kernel instantiation gvec_create picks for this board size (gvec_kernels.hip pick_variant)."""
+    maxp = next(m for m in (2, 4, 8) if m >= p)
+    nslot = next(n for n in (1, 2, 4, 7, 10, 16) if n * 64 >= w * h)
+    odd = w * h <= 32 * (2 * nslot - 1)
+    return f"gvec::step_kernel<{maxp}, {nslot}, true, {'true' if odd else 'false'}>"
+
+
 def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
     """Times the CPU oracle (test infrastructure) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -257,7 +265,7 @@ def main():
                        "envs_per_gpu": B, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
                        "gather_envs_per_step": (args.gather_envs if n > 1 else 0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "gvec::step_kernel<4,7,true>", "algorithmic_bytes_per_env_step": abytes,
+                         "traffic": traffic, "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
                          "units_per_launch": B, "kernel_ms": kernel_ms},
         }
         if fused:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of two builds of libgvec_hip.so in ONE process on ONE device
-(cdna_hip_programming.md 5.4 rule 24).   usage: scripts/ab_bench.py libA.so libB.so [libC.so ...] [rounds] [steps]"""
+(cdna_hip_programming.md 5.4 rule 24).   usage: scripts/ab_bench.py [--dup] libA.so libB.so [libC.so ...] [rounds] [steps]"""
 import statistics as st
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,9 @@ from generalsreinforcementlearning_amd import _lib
 from generalsreinforcementlearning_amd.vec_engine import VecEngine
 
 paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+if "--dup" in sys.argv:  # every build twice, interleaved: shows how much of a difference is buffer placement / order
+    sys.argv.remove("--dup")
+    paths = paths + paths
 nums = [int(a) for a in sys.argv[1:] if not a.endswith(".so")]
 rounds = nums[0] if len(nums) > 0 else 7
 steps = nums[1] if len(nums) > 1 else 100

@@ -7,8 +7,10 @@ TAG=${1:-run}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+# kernel trace: bench.py's default step counts, so the kernel's average here is the one bench.py reports
+T="python3 bench.py --no-cpu-baseline --no-fused $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $T > $OUT/trace.log 2>&1
 B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fused $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 # PMC passes: counters only (never combined with sys/hip/hsa tracing)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
