@@ -81,7 +81,7 @@ def load_from(path):
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.gvec_abi_version() != 1:
+    if L.gvec_abi_version() != 2:
         raise GvecError(-1, "ABI version mismatch")
     return L
 

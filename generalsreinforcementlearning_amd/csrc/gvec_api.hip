@@ -261,7 +261,7 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   h->fd = (h->stride <= 32 * (2 * h->var.nslot - 1)) ? 2 * h->var.nslot - 1 : 2 * h->var.nslot;
   h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 5) * h->fd, 4);
   h->army_dw = h->var.nslot * 64;
-  h->mask_bytes = (int)round_up((size_t)(h->stride + 1) / 2, 16);
+  h->mask_bytes = 16 * h->fd;  // four direction bit-planes of fd dwords per player
   h->mask_dw = h->mask_bytes / 4;
   h->stream = nullptr;
   const size_t B = (size_t)cfg->num_envs;

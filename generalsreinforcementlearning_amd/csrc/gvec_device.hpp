@@ -147,15 +147,6 @@ struct ColumnPatternTable {
 };
 __device__ const ColumnPatternTable kColumnPattern{};
 
-// spread bit i of the low byte to bit 4*i
-__device__ __forceinline__ uint32_t spread4(uint32_t x) {
-  x &= 0xFFu;
-  x = (x | (x << 12)) & 0x000F000Fu;
-  x = (x | (x << 6)) & 0x03030303u;
-  x = (x | (x << 3)) & 0x11111111u;
-  return x;
-}
-
 // =========================================================================================
 template <int MAXP, int NSLOT>
 struct Board {
@@ -613,37 +604,42 @@ struct Board {
   }
 
   // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73) --------------------
-  // out[p][k]: lane j holds bits [32*(j+64k), +32) of player p's mask, bit i = action
-  // (y*W+x)*4+d with d = 0 up, 1 right, 2 down, 3 left (H10).  Output dword j covers tiles
-  // 8j..8j+7 = byte j&3 of flat dword j>>2: one bpermute per plane, then a x4 bit spread.
-  __device__ __forceinline__ uint32_t flat_byte(uint32_t plane, int pass) const {
-    const int j = lane_id() + 64 * pass;
-    return __builtin_amdgcn_ubfe(bperm((j >> 2) << 2, plane), (uint32_t)(8 * (j & 3)), 8u);
-  }
-  // SERIALIZER = false: Engine.GetLegalActionMask (rules/legal_moves.go:19-73).
+  // A player's packed mask is FOUR DIRECTION BIT-PLANES of fd dwords each: bit t of plane d = action
+  // (y*W+x)*4 + d of the reference, t = y*W + x.  Plane d is then just
+  //     (listed & owned & army > 1)  &  ("the neighbour in direction d is on the board, not a mountain")
+  // in the flat domain - two ANDs - and the row [d][i] is laid on lanes j = d*fd + i with one
+  // ds_bpermute per plane (lane j reads flat lane j mod fd), so that lane j stores dword j: one
+  // coalesced store per player.  out[p][k]: lane l holds dword l + 64k of player p's row.
+  // SERIALIZER = false: Engine.GetLegalActionMask, d = 0 up, 1 right, 2 down, 3 left (H10).
   // SERIALIZER = true : Serializer.GenerateActionMask (internal/experience/serializer.go:112-176):
-  //   board owner (not the list), army >= 2, no Alive check, directions 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
+  //   board owner (not the list), army >= 2, no Alive check, d = 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
   template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS]) const {
+  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
     uint32_t gt1 = 0u;  // army > 1 as a flat plane
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
     const uint32_t notm = ~mtn & valid;  // in-board, not a mountain (Validate :58-64,:96-98)
     const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);                  // target y-1 / y+1
     const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;  // target x+1 / x-1
+    const uint32_t ok1 = SERIALIZER ? ok_dn : ok_rt, ok2 = SERIALIZER ? ok_lf : ok_dn, ok3 = SERIALIZER ? ok_rt : ok_lf;
+    uint32_t src[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1
+      const uint32_t m = SERIALIZER ? (own[p] & gt1) : (lst[p] & own[p] & gt1);
+      src[p] = (SERIALIZER || ((alive >> p) & 1u)) ? m : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < MPASS; ++k) {
-      const uint32_t s_up = spread4(flat_byte(ok_up, k)), s_rt = spread4(flat_byte(ok_rt, k));
-      const uint32_t s_dn = spread4(flat_byte(ok_dn, k)), s_lf = spread4(flat_byte(ok_lf, k));
-      const uint32_t okn = SERIALIZER ? (s_up | (s_dn << 1) | (s_lf << 2) | (s_rt << 3)) : (s_up | (s_rt << 1) | (s_dn << 2) | (s_lf << 3));
+      const int j = lane_id() + 64 * k;
+      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
+      const int addr = (j - d * fd) << 2;  // flat lane j mod fd
+      // cross-lane reads: all unconditional
+      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
+      uint32_t okp = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
+      okp = (j < 4 * fd) ? okp : 0u;
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) {
-        // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1
-        const uint32_t src = SERIALIZER ? (own[p] & gt1) : (lst[p] & own[p] & gt1);
-        const uint32_t cb = flat_byte(src, k);  // cross-lane: keep it unconditional
-        const uint32_t can = (SERIALIZER || ((alive >> p) & 1u)) ? cb : 0u;
-        out[p][k] = (spread4(can) * 15u) & okn;
-      }
+      for (int p = 0; p < MAXP; ++p) out[p][k] = bperm(addr, src[p]) & okp;
     }
   }
 

@@ -21,10 +21,11 @@ __device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
 }
 
 // All hashing / coordinate arithmetic runs on lanes (lane p = player p); only the choice of the
-// k-th legal move needs a wave-wide scan per player.
+// k-th legal move needs a wave-wide scan per player.  "k-th" counts the set bits of the player's packed
+// mask row in storage order: direction plane 0 tile 0.., then plane 1, ... (fd = dwords per plane).
 template <int MAXP, int NSLOT>
 __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
-                                             const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], uint32_t ek,
+                                             const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], int fd, uint32_t ek,
                                              int invalid_permille, uint32_t& alo, uint32_t& ahi) {
   constexpr int MPASS = Board<MAXP, NSLOT>::MPASS;
   const int lane = lane_id();
@@ -66,9 +67,11 @@ __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
         found = true;
       }
     }
-    const int idx = 32 * jj + select_kth(word, kk - below);
-    t = (lane == p) ? (idx >> 2) : t;
-    d = (lane == p) ? (idx & 3) : d;
+    // row dword jj = direction plane jj / fd, tiles 32 * (jj % fd) ..
+    const int dd = (jj >= fd ? 1 : 0) + (jj >= 2 * fd ? 1 : 0) + (jj >= 3 * fd ? 1 : 0);
+    const int tt = 32 * (jj - dd * fd) + select_kth(word, kk - below);
+    t = (lane == p) ? tt : t;
+    d = (lane == p) ? dd : d;
   }
   const int y = (t * b.recipW) >> 16, x = t - y * b.W;
   const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     uint32_t alo = 0u, ahi = 0u;
     if constexpr (AGENT) {
       load_masks<MAXP, NSLOT>(lm, A, env);
-      agent_sample<MAXP, NSLOT>(b, lm, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
+      agent_sample<MAXP, NSLOT>(b, lm, FD, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
       if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
     } else if (lane < A.pstride) {
       const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
-    b.template legal_masks<false>(lm);
+    b.template legal_masks<false>(lm, FD);
     store_masks<MAXP, NSLOT>(lm, A, env);
   }
 }
@@ -243,17 +246,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   // The hot inner loop plays turns while the game is live; the rare events (game over: re-deal from
   // the pool, or freeze) sit in the outer loop so they do not shape the inner loop's registers.
   for (;;) {
-    b.template legal_masks<false>(lm);  // the masks of the CURRENT state: the agent's input, the output at the end
+    b.template legal_masks<false>(lm, A.fd);  // the masks of the CURRENT state: the agent's input, the output at the end
     while (k < A.turns && !(b.hflags & HF_DONE)) {
       uint32_t alo, ahi;
-      agent_sample<MAXP, NSLOT>(b, lm, ek, A.invalid_permille, alo, ahi);
+      agent_sample<MAXP, NSLOT>(b, lm, A.fd, ek, A.invalid_permille, alo, ahi);
       bool aborted;
       err = b.turn_step(alo, ahi, A, aborted);
       n_steps += 1u;
       n_abort += aborted ? 1u : 0u;
       n_done += (b.hflags & HF_DONE) ? 1u : 0u;
       ++k;
-      b.template legal_masks<false>(lm);
+      b.template legal_masks<false>(lm, A.fd);
     }
     if (k >= A.turns) break;
     if (!can_redeal) {
@@ -287,11 +290,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
   uint32_t lm[MAXP][MPASS];
-  if constexpr (MODE == 2) b.template legal_masks<true>(lm);
-  else b.template legal_masks<false>(lm);
+  if constexpr (MODE == 2) b.template legal_masks<true>(lm, A.fd);
+  else b.template legal_masks<false>(lm, A.fd);
   if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
-    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
+    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, A.fd, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
   } else {
 #pragma unroll
@@ -810,7 +813,6 @@ __global__ void selftest_kernel(int32_t* out) {
   if (wave_scan_add(v) != expect) fail = fail ? fail : 3;
   if (wave_sum(v) != (uint32_t)(63 * 64 / 2 * 3 + 64)) fail = fail ? fail : 4;
   if (bperm(4 * ((lane * 7) & 63), v) != (uint32_t)(((lane * 7) & 63) * 3 + 1)) fail = fail ? fail : 5;
-  if (spread4(0xA5u) != 0x10100101u) fail = fail ? fail : 6;
   {  // select_kth is a wave-wide operation on uniform inputs
     const bool bad = select_kth(0x80000105u, 0) != 0 || select_kth(0x80000105u, 1) != 2 || select_kth(0x80000105u, 2) != 8 ||
                      select_kth(0x80000105u, 3) != 31;

@@ -158,8 +158,11 @@ func (e *VecEngine) GetLegalActionMask(env, playerID, w, h int) []bool {
 		return mask // engine.go:273-276
 	}
 	bits := e.maskBits[(env*e.cfg.Players+playerID)*e.maskBytes:]
-	for i := range mask {
-		mask[i] = bits[i>>3]&(1<<uint(i&7)) != 0
+	plane := e.maskBytes / 4 // four direction bit-planes (generals_vec.h, gvec_step)
+	for t := 0; t < w*h; t++ {
+		for d := 0; d < 4; d++ {
+			mask[t*4+d] = bits[d*plane+(t>>3)]&(1<<uint(t&7)) != 0
+		}
 	}
 	return mask
 }

@@ -101,7 +101,9 @@ class VecEngine {
     if (playerID < 0 || playerID >= cfg_.Players) return out;  // engine.go:273-276
     check(gvec_legal_mask(h_, mask_.data(), GVEC_MEM_HOST), "gvec_legal_mask");
     const uint8_t* bits = &mask_[(static_cast<size_t>(env) * cfg_.Players + playerID) * mask_bytes_];
-    for (size_t i = 0; i < out.size(); ++i) out[i] = (bits[i >> 3] >> (i & 7)) & 1u;
+    const size_t plane = static_cast<size_t>(mask_bytes_) / 4;  // four direction bit-planes (generals_vec.h, gvec_step)
+    for (size_t t = 0; t < static_cast<size_t>(w) * h; ++t)
+      for (size_t d = 0; d < 4; ++d) out[t * 4 + d] = (bits[d * plane + (t >> 3)] >> (t & 7)) & 1u;
     return out;
   }
 

@@ -40,10 +40,16 @@ def make_actions(num_envs, max_players, moves=()):
 
 
 def unpack_legal_bits(bits, width, height):
-    """[..., mask_bytes] packed bits -> [..., W*H*4] bool in Engine.GetLegalActionMask order
-    (index (y*W+x)*4+d, d = 0 up, 1 right, 2 down, 3 left; rules/legal_moves.go:13-18)."""
-    u = np.unpackbits(np.ascontiguousarray(bits), axis=-1, bitorder="little")
-    return u[..., : width * height * 4].astype(bool)
+    """[..., mask_bytes] packed mask -> [..., W*H*4] bool in Engine.GetLegalActionMask order
+    (index (y*W+x)*4+d, d = 0 up, 1 right, 2 down, 3 left; rules/legal_moves.go:13-18).
+
+    Packed form (include/generals_vec.h): four direction bit-planes of mask_bytes/4 bytes each;
+    bit t (LSB first) of plane d is action (t, d), t = y*W + x."""
+    bits = np.ascontiguousarray(bits)
+    plane = bits.shape[-1] // 4
+    u = np.unpackbits(bits.reshape(bits.shape[:-1] + (4, plane)), axis=-1, bitorder="little")  # [..., d, t]
+    u = u[..., : width * height]
+    return np.moveaxis(u, -2, -1).reshape(bits.shape[:-1] + (width * height * 4,)).astype(bool)
 
 
 def _ptr(a):

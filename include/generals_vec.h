@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GVEC_ABI_VERSION 1
+#define GVEC_ABI_VERSION 2
 
 /* limits of this build */
 #define GVEC_MAX_PLAYERS 8   /* VisibleBitfield is carried as a u8 per tile            */
@@ -154,7 +154,7 @@ const char* gvec_last_error(void);
 /* sizes */
 int32_t gvec_num_envs(const gvec_handle* h);
 int32_t gvec_tile_stride(const gvec_handle* h);   /* max_width*max_height              */
-int32_t gvec_mask_bytes(const gvec_handle* h);    /* ceil(4*tile_stride/8) per player, padded to a multiple of 16 */
+int32_t gvec_mask_bytes(const gvec_handle* h);    /* bytes of one player's packed mask: 4 direction bit-planes (see gvec_step) */
 int64_t gvec_state_bytes_per_env(const gvec_handle* h); /* resident device bytes / env */
 
 /* ---- reset: EngineInitializer.Initialize minus mapgen -------------------------
@@ -188,9 +188,12 @@ int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed,
  * actions[B][max_players]; err[B] receives the sentinel of the first failing move
  * in PlayerID order (processor/action_processor.go:36-99), GVEC_ERR_GAME_OVER for
  * a finished env (turn_processor.go:95-113), else 0.
- * legal_bits (may be NULL): [B][max_players][mask_bytes], bit i of player p's mask
- * = Engine.GetLegalActionMask(p)[i], i = (y*W+x)*4 + d, d = 0 up,1 right,2 down,
- * 3 left (rules/legal_moves.go:13-18,66), computed on the post-step state. */
+ * legal_bits (may be NULL): [B][max_players][mask_bytes], computed on the post-step
+ * state.  One player's mask is FOUR DIRECTION BIT-PLANES of mask_bytes/4 bytes each,
+ * d = 0 up, 1 right, 2 down, 3 left (rules/legal_moves.go:13-18,66): bit t (LSB
+ * first) of plane d = Engine.GetLegalActionMask(p)[t*4 + d], t = y*W + x.  (Go's
+ * []bool index order is a transpose of this: see INTEGRATION.md for the 3-line
+ * unpack.)  ABI version 2: version 1 packed bit i = mask[i]. */
 int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err,
                   uint8_t* legal_bits, int32_t mem);
 

@@ -528,7 +528,7 @@ ora_batch* ora_batch_new(int32_t num_envs, int32_t max_w, int32_t max_h, int32_t
   ora_batch* b = (ora_batch*)calloc(1, sizeof(ora_batch));
   b->num_envs = num_envs; b->max_w = max_w; b->max_h = max_h; b->max_p = max_p;
   b->stride = max_w * max_h;
-  b->mask_bytes = (((b->stride + 1) / 2) + 15) / 16 * 16; /* = gvec_mask_bytes(): ceil(4*stride/8) padded to 16 B */
+  b->mask_bytes = ora_mask_bytes(b->stride);
   if (params) b->params = *params; else ora_params_default(&b->params);
   b->env = (ora_engine**)calloc((size_t)num_envs, sizeof(ora_engine*));
   b->episode = (int32_t*)calloc((size_t)num_envs, sizeof(int32_t));
@@ -557,13 +557,26 @@ int32_t ora_batch_reset(ora_batch* b, const int32_t* env_ids, int32_t n, const i
   return 0;
 }
 
+/* The packed mask of include/generals_vec.h: per player four direction bit-planes of mask_bytes/4
+ * bytes; bit t (LSB first, little-endian dwords) of plane d = mask[(t)*4 + d] of the reference. */
+int32_t ora_mask_bytes(int32_t stride) {
+  static const int slots[6] = {1, 2, 4, 7, 10, 16}; /* 64-tile slots of the kernel variants (gvec_kernels.hip pick_variant) */
+  int need = (stride + 63) / 64, n = 16;
+  for (int i = 0; i < 6; i++) if (slots[i] >= need) { n = slots[i]; break; }
+  int fd = (stride <= 32 * (2 * n - 1)) ? 2 * n - 1 : 2 * n; /* dwords per plane (gvec_api.hip) */
+  return 16 * fd;
+}
+static void pack_bool_mask(const uint8_t* mask /* [n][4] */, int n, uint8_t* o, int mask_bytes) {
+  int plane = mask_bytes / 4;
+  for (int t = 0; t < n; t++)
+    for (int d = 0; d < 4; d++)
+      if (mask[t * 4 + d]) o[d * plane + (t >> 3)] |= (uint8_t)(1u << (t & 7));
+}
 static void pack_legal_bits(const ora_batch* b, const ora_engine* e, uint8_t* out /* [max_p][mask_bytes] */, uint8_t* scratch) {
   memset(out, 0, (size_t)b->max_p * (size_t)b->mask_bytes);
-  int n4 = e->board->w * e->board->h * 4;
   for (int p = 0; p < e->num_players; p++) {
     ora_engine_legal_mask(e, p, scratch);
-    uint8_t* o = out + (size_t)p * (size_t)b->mask_bytes;
-    for (int i = 0; i < n4; i++) if (scratch[i]) o[i >> 3] |= (uint8_t)(1u << (i & 7));
+    pack_bool_mask(scratch, e->board->w * e->board->h, out + (size_t)p * (size_t)b->mask_bytes, b->mask_bytes);
   }
 }
 
@@ -843,11 +856,10 @@ int32_t ora_batch_serializer_mask(ora_batch* b, uint8_t* bits) {
   memset(bits, 0, (size_t)b->num_envs * (size_t)b->max_p * (size_t)b->mask_bytes);
   for (int i = 0; i < b->num_envs; i++) {
     const ora_engine* e = b->env[i];
-    int n4 = e->board->w * e->board->h * 4;
     for (int p = 0; p < e->num_players; p++) {
       ora_serializer_mask(e, p, scratch);
-      uint8_t* o = bits + ((size_t)i * (size_t)b->max_p + (size_t)p) * (size_t)b->mask_bytes;
-      for (int k = 0; k < n4; k++) if (scratch[k]) o[k >> 3] |= (uint8_t)(1u << (k & 7));
+      pack_bool_mask(scratch, e->board->w * e->board->h, bits + ((size_t)i * (size_t)b->max_p + (size_t)p) * (size_t)b->mask_bytes,
+                     b->mask_bytes);
     }
   }
   free(scratch);
@@ -887,9 +899,12 @@ static void agent_env(const ora_batch* b, const ora_engine* e, uint32_t ek, int3
       int cnt = 0;
       for (int i = 0; i < n4; i++) cnt += scratch[i];
       if (cnt == 0) continue;
-      int k = (int)mulhi32(h2, (uint32_t)cnt), idx = -1;
-      for (int i = 0; i < n4; i++) if (scratch[i]) { if (k == 0) { idx = i; break; } k--; }
-      t = idx >> 2; d = idx & 3;
+      /* k-th legal action in the order of the packed mask: direction plane 0 (up) tile 0.., then 1, 2, 3 */
+      int k = (int)mulhi32(h2, (uint32_t)cnt);
+      t = -1; d = 0;
+      for (int dd = 0; dd < 4 && t < 0; dd++)
+        for (int tt = 0; tt < w * h; tt++)
+          if (scratch[tt * 4 + dd]) { if (k == 0) { t = tt; d = dd; break; } k--; }
     }
     int x = t % w, y = t / w;
     out[p].from_x = (int8_t)x; out[p].from_y = (int8_t)y;

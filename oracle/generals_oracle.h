@@ -158,6 +158,7 @@ void       ora_city_changes(const ora_engine* prev, const ora_engine* cur, int32
 int32_t    ora_batch_experience_begin(ora_batch* b);
 int32_t    ora_batch_rewards(ora_batch* b, float* rewards /*[B][max_p]*/, uint8_t* done /*[B] or NULL*/);
 int32_t    ora_batch_observe(ora_batch* b, int32_t player, float* out /*[B][9*stride]*/);
+int32_t    ora_mask_bytes(int32_t stride);  /* = gvec_mask_bytes(): 4 direction bit-planes per player */
 int32_t    ora_batch_serializer_mask(ora_batch* b, uint8_t* bits /*[B][max_p][mask_bytes]*/);
 
 /* ---- synthetic inputs (the build's own spec; no reference counterpart

@@ -290,7 +290,7 @@ class OracleBatch:
         self.L = lib()
         self.B, self.max_w, self.max_h, self.max_p = num_envs, max_w, max_h, max_p
         self.stride = max_w * max_h
-        self.mask_bytes = (((self.stride + 1) // 2) + 15) // 16 * 16  # = gvec_mask_bytes()
+        self.mask_bytes = int(self.L.ora_mask_bytes(self.stride))  # = gvec_mask_bytes()
         self._prm = params(fog, prod, interval)
         self.b = self.L.ora_batch_new(num_envs, max_w, max_h, max_p, C.byref(self._prm))
 

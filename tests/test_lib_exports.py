@@ -24,7 +24,7 @@ def test_header_symbols_exported(built):
     L = g.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.gvec_abi_version() == 1
+    assert L.gvec_abi_version() == 2
 
 
 def test_config_defaults_match_reference(built):

@@ -40,8 +40,8 @@ class OracleBackend:
         return {k: v[0] for k, v in self.e.read_state().items()}
 
     def mask(self, p):
-        bits = self.e.legal_mask()[0, p]
-        return np.unpackbits(bits, bitorder="little")[: W * H * 4].astype(bool)
+        from generalsreinforcementlearning_amd.vec_engine import unpack_legal_bits
+        return unpack_legal_bits(self.e.legal_mask()[0, p], W, H)
 
 
 class HipBackend(OracleBackend):
