@@ -30,6 +30,17 @@ def action_to_index(actions, width):
     return (fy * width + fx) * 4 + d
 
 
+def index_to_action(index, width, height):
+    """Serializer.IndexToAction (internal/experience/serializer.go:201-223): -> (from_x, from_y, to_x, to_y);
+    like the Go code, no bounds check on the destination."""
+    index = np.asarray(index, np.int64)
+    d, t = index % 4, index // 4
+    fx, fy = t % width, t // width
+    tx = fx + np.where(d == 3, 1, 0) - np.where(d == 2, 1, 0)
+    ty = fy + np.where(d == 1, 1, 0) - np.where(d == 0, 1, 0)
+    return fx, fy, tx, ty
+
+
 class VecExperienceCollector:
     """Usage per turn:  c.before_step(); err = engine.step(actions); batch = c.after_step(actions)"""
 

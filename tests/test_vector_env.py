@@ -249,3 +249,39 @@ def test_vector_env_matches_scalar_restatement_on_hip_states():
             assert np.array_equal(obs[e], ref_get_observation(tiles, 10, 10, 0, int(info["turn"][e]), 100))
             assert np.array_equal(info["valid_actions_mask"][e], ref_valid_mask(tiles, 10, 10, 0))
     env.close()
+
+
+# ---- serializer action index (internal/experience/serializer.go:179-223), reference vectors ----
+def _kats(kind):
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))
+    return [pytest.param(c, id=c["name"]) for c in d["cases"] if c["kind"] == kind]
+
+
+def _one_action(fx, fy, tx, ty):
+    from generalsreinforcementlearning_amd.vec_engine import ACTION_DTYPE
+    a = np.zeros(1, ACTION_DTYPE)
+    a["from_x"], a["from_y"], a["to_x"], a["to_y"], a["flags"] = fx, fy, tx, ty, 1
+    return a
+
+
+@pytest.mark.parametrize("c", _kats("action_to_index"))
+def test_golden_action_to_index(c):
+    from generalsreinforcementlearning_amd.experience import action_to_index
+    assert int(action_to_index(_one_action(*c["from"], *c["to"]), c["w"])[0]) == c["expect"]
+
+
+@pytest.mark.parametrize("c", _kats("index_to_action"))
+def test_golden_index_to_action(c):
+    from generalsreinforcementlearning_amd.experience import action_to_index, index_to_action
+    fx, fy, tx, ty = (int(v) for v in index_to_action(c["index"], c["w"], c["h"]))
+    assert [fx, fy] == c["expect"]["from"] and [tx, ty] == c["expect"]["to"]
+    assert int(action_to_index(_one_action(fx, fy, tx, ty), c["w"])[0]) == c["index"]  # round trip
+
+
+@pytest.mark.parametrize("c", _kats("action_indices_distinct"))
+def test_golden_action_indices_distinct(c):
+    from generalsreinforcementlearning_amd.experience import action_to_index
+    idx = {int(action_to_index(_one_action(*m), c["w"])[0]) for m in c["moves"]}
+    assert len(idx) == c["expect_distinct"]
