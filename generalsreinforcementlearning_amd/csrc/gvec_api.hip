@@ -42,6 +42,7 @@ struct gvec_handle {
   gvec_action* d_actions = nullptr;
   int32_t* d_err = nullptr;
   int32_t* d_status = nullptr;
+  uint32_t agent_noop = 6554u, agent_half = 19661u;  // gvec_set_agent_mix
   unsigned long long* d_counters = nullptr;  // [6]: before[3], after[3]
   uint32_t* d_snap = nullptr;                // experience snapshots [B][snap_dw] (allocated on first use)
   int snap_dw = 0;
@@ -90,6 +91,8 @@ StepArgs base_args(const gvec_handle* h) {
   a.prod_normal = h->cfg.prod_normal;
   a.interval = h->cfg.normal_growth_interval;
   a.turns = 1;
+  a.agent_noop = h->agent_noop;
+  a.agent_half = h->agent_half;
   a.pool_seed_lo = (uint32_t)h->pool_seed;
   a.pool_seed_hi = (uint32_t)(h->pool_seed >> 32);
   if (h->cfg.auto_reset && h->pool_size > 0) a.flags |= KF_AUTORESET;
@@ -613,6 +616,17 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
     stats->games_finished = (int64_t)(c[5] - c[2]);
     stats->captures = 0;
   }
+  return GVEC_OK;
+}
+
+int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_per_65536) {
+  if (!h) return GVEC_E_INVALID;
+  if (noop_per_65536 < 0 || noop_per_65536 > 65536 || half_per_65536 < 0 || half_per_65536 > 65536) {
+    set_err("gvec_set_agent_mix: thresholds must be in [0, 65536]");
+    return GVEC_E_INVALID;
+  }
+  h->agent_noop = (uint32_t)noop_per_65536;
+  h->agent_half = (uint32_t)half_per_65536;
   return GVEC_OK;
 }
 

@@ -26,14 +26,15 @@ __device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
 template <int MAXP, int NSLOT>
 __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
                                              const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], int fd, uint32_t ek,
-                                             int invalid_permille, uint32_t& alo, uint32_t& ahi) {
+                                             const StepArgs& A, uint32_t& alo, uint32_t& ahi) {
+  const int invalid_permille = A.invalid_permille;
   constexpr int MPASS = Board<MAXP, NSLOT>::MPASS;
   const int lane = lane_id();
   const uint32_t h1 = fmix32(ek + (uint32_t)b.turn * 0x9E3779B1u + (uint32_t)lane * 0x7F4A7C15u + 0x165667B1u);
   const uint32_t h2 = fmix32(h1 ^ 0x68E31DA4u);
   const uint32_t h3 = fmix32(h2 + 0xB5297A4Du);
-  bool act = lane < b.P && ((b.alive >> lane) & 1u) && !((h1 & 0xFFFFu) < 6554u);  // no-op with p ~ 0.1
-  const bool half = (h1 >> 16) < 19661u;                                             // p ~ 0.3
+  bool act = lane < b.P && ((b.alive >> lane) & 1u) && !((h1 & 0xFFFFu) < A.agent_noop);  // no-op (default p ~ 0.1)
+  const bool half = (h1 >> 16) < A.agent_half;                                        // default p ~ 0.3
   const bool inv = invalid_permille > 0 && (int)mulhi32(h3, 1000u) < invalid_permille;
   int t = (int)mulhi32(h2, (uint32_t)b.N);  // unchecked move (H5 stress) unless replaced below
   int d = (int)(h3 & 3u);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     uint32_t alo = 0u, ahi = 0u;
     if constexpr (AGENT) {
       load_masks<MAXP, NSLOT>(lm, A, env);
-      agent_sample<MAXP, NSLOT>(b, lm, FD, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
+      agent_sample<MAXP, NSLOT>(b, lm, FD, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
       if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
     } else if (lane < A.pstride) {
       const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
     b.template legal_masks<false>(lm, A.fd);  // the masks of the CURRENT state: the agent's input, the output at the end
     while (k < A.turns && !(b.hflags & HF_DONE)) {
       uint32_t alo, ahi;
-      agent_sample<MAXP, NSLOT>(b, lm, A.fd, ek, A.invalid_permille, alo, ahi);
+      agent_sample<MAXP, NSLOT>(b, lm, A.fd, ek, A, alo, ahi);
       bool aborted;
       err = b.turn_step(alo, ahi, A, aborted);
       n_steps += 1u;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   else b.template legal_masks<false>(lm, A.fd);
   if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
-    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, A.fd, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A.invalid_permille, alo, ahi);
+    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, A.fd, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
   } else {
 #pragma unroll

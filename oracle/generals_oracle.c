@@ -518,6 +518,7 @@ const uint8_t* ora_engine_vis_changed(const ora_engine* e) { return e->vis_chang
 struct ora_batch {
   ora_engine** prev;    /* experience snapshots (GameState.Clone before the step) */
   int32_t num_envs, max_w, max_h, max_p, stride, mask_bytes;
+  uint32_t agent_noop, agent_half; /* gvec_set_agent_mix thresholds */
   ora_params params;
   ora_engine** env;
   int32_t* episode;     /* re-deal counter per env (auto-reset) */
@@ -529,6 +530,7 @@ ora_batch* ora_batch_new(int32_t num_envs, int32_t max_w, int32_t max_h, int32_t
   b->num_envs = num_envs; b->max_w = max_w; b->max_h = max_h; b->max_p = max_p;
   b->stride = max_w * max_h;
   b->mask_bytes = ora_mask_bytes(b->stride);
+  b->agent_noop = 6554u; b->agent_half = 19661u;
   if (params) b->params = *params; else ora_params_default(&b->params);
   b->env = (ora_engine**)calloc((size_t)num_envs, sizeof(ora_engine*));
   b->episode = (int32_t*)calloc((size_t)num_envs, sizeof(int32_t));
@@ -886,8 +888,8 @@ static void agent_env(const ora_batch* b, const ora_engine* e, uint32_t ek, int3
   for (int p = 0; p < e->num_players; p++) {
     if (!e->players[p].alive) continue;
     uint32_t h1 = ora_fmix32(ek + (uint32_t)e->turn * 0x9E3779B1u + (uint32_t)p * 0x7F4A7C15u + 0x165667B1u);
-    if ((h1 & 0xFFFFu) < 6554u) continue;                    /* no-op, p ~ 0.1 */
-    int half = (h1 >> 16) < 19661u;                          /* p ~ 0.3 */
+    if ((h1 & 0xFFFFu) < b->agent_noop) continue;             /* no-op, default p ~ 0.1 */
+    int half = (h1 >> 16) < b->agent_half;                   /* default p ~ 0.3 */
     uint32_t h2 = ora_fmix32(h1 ^ 0x68E31DA4u);
     uint32_t h3 = ora_fmix32(h2 + 0xB5297A4Du);
     int t, d;
@@ -913,6 +915,10 @@ static void agent_env(const ora_batch* b, const ora_engine* e, uint32_t ek, int3
   }
 }
 
+int32_t ora_batch_set_agent_mix(ora_batch* b, int32_t noop_per_65536, int32_t half_per_65536) {
+  b->agent_noop = (uint32_t)noop_per_65536; b->agent_half = (uint32_t)half_per_65536;
+  return 0;
+}
 int32_t ora_batch_agent_actions(ora_batch* b, uint64_t seed, int32_t invalid_permille, ora_action8* actions, int32_t threads) {
   (void)threads;
 #ifdef _OPENMP

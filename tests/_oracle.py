@@ -126,6 +126,7 @@ def lib():
     L.ora_batch_write_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(StateView)]
     L.ora_fmix32.restype = C.c_uint32
     L.ora_fmix32.argtypes = [C.c_uint32]
+    L.ora_batch_set_agent_mix.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.ora_batch_agent_actions.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32]
     L.ora_mapgen.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i8p, u8p]
     L.ora_batch_set_pool.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, i32p, i32p, i32p]
@@ -321,6 +322,9 @@ class OracleBatch:
         bits = np.zeros((self.B, self.max_p, self.mask_bytes), np.uint8)
         self.L.ora_batch_legal_mask(self.b, _ptr(bits, u8p), threads)
         return bits
+
+    def set_agent_mix(self, noop_per_65536=6554, half_per_65536=19661):
+        self.L.ora_batch_set_agent_mix(self.b, int(noop_per_65536), int(half_per_65536))
 
     def agent_actions(self, seed, invalid_permille=0, threads=1):
         acts = np.zeros((self.B, self.max_p), ACTION_DTYPE)

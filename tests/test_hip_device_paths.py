@@ -113,3 +113,35 @@ def test_empty_ranges_and_zero_turn_rollout(g):
     st = eng.game_state(3, 0)  # n = 0
     assert all(len(v) == 0 for v in st.values())
     assert eng.rollout(0, 1)["env_steps"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mix", [(0, 0), (32768, 65536), (65536, 0)], ids=["reference_random_agent", "half_always", "never_moves"])
+def test_agent_mix_matches_oracle(g, mix):
+    """gvec_set_agent_mix: (0, 0) is the reference's random opponent (always a full move over the legal ones)."""
+    B, w, h, p = 128, 12, 12, 3
+    army, owner, typ, ww, hh, pp = H.gen_boards(77, [(w, h, p)] * B, w, h)
+    eng = g.VecEngine(B, w, h, p)
+    ora = O.OracleBatch(B, w, h, p)
+    for e in (eng, ora):
+        e.reset(army, owner, typ, ww, hh, pp)
+        e.set_agent_mix(*mix)
+    for k in range(40):
+        ha, oa = eng.agent_actions(5), ora.agent_actions(5)
+        assert np.array_equal(ha, oa), f"turn {k}"
+        flags = ha["flags"]
+        if mix == (0, 0):
+            st = ora.read_state()
+            has_move = ora.legal_mask().reshape(B, p, -1).any(-1)
+            assert np.array_equal((flags & 1).astype(bool), has_move & st["alive"].astype(bool) & ~st["done"].astype(bool)[:, None])
+            assert not (flags & 2).any()          # never a half move
+        if mix == (65536, 0):
+            assert not flags.any()
+        if mix == (32768, 65536):
+            assert ((flags & 1) == 0).any() and (flags[(flags & 1) == 1] & 2).all()
+        assert np.array_equal(eng.step(ha), ora.step(oa))
+    st = eng.rollout(60, 9, 0, fused=True)
+    assert st["env_steps"] == ora.rollout(60, 9, 0)
+    H.assert_states_equal(eng.game_state(), ora.read_state(), f"agent mix {mix}")
+    with pytest.raises(g.GvecError):
+        eng.set_agent_mix(-1, 0)
