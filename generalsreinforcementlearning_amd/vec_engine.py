@@ -192,7 +192,8 @@ class VecEngine:
     # ---- synthetic random-agent rollouts ----------------------------------------------------------
     def set_agent_mix(self, noop_per_65536=6554, half_per_65536=19661):
         """Random-agent mix for rollout / agent_actions: P(no-op) = noop/65536, P(half move) = half/65536.
-        (0, 0) is the reference's random opponent: always a full move, uniform over the legal ones."""
+        (45875, 19661) are the rates of the reference's game.GenerateRandomActions (demo_helpers.go:20,44);
+        (0, 0) always plays a full move, uniform over the legal ones."""
         check(self.L.gvec_set_agent_mix(self.h, int(noop_per_65536), int(half_per_65536)), "gvec_set_agent_mix")
 
     def agent_actions(self, seed, invalid_permille=0):

@@ -229,8 +229,10 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed,
                      gvec_rollout_stats* stats);
 /* The agent's mix: a player sits a turn out when (draw & 0xFFFF) < noop_per_65536 (default 6554,
  * p = 0.1) and moves half its army when (draw >> 16) < half_per_65536 (default 19661, p = 0.3).
- * (0, 0) is the reference's random opponent: always a full move, uniform over the legal ones
- * (python/generals_agent/random_agent.py).  Applies to gvec_rollout and gvec_agent_actions. */
+ * (45875, 19661) are the rates of the reference's game.GenerateRandomActions (demo_helpers.go:20,44:
+ * a player acts with p = 0.3, MoveAll with p = 0.7); (0, 0) always plays a full move, uniform over
+ * the legal ones.  The default acts three times as often as the Go helper: more work per turn.
+ * Applies to gvec_rollout and gvec_agent_actions. */
 int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_per_65536);
 /* The agent alone: fills actions[B][max_players] for the current state/turn. */
 int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille,

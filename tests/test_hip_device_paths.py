@@ -116,9 +116,10 @@ def test_empty_ranges_and_zero_turn_rollout(g):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mix", [(0, 0), (32768, 65536), (65536, 0)], ids=["reference_random_agent", "half_always", "never_moves"])
+@pytest.mark.parametrize("mix", [(0, 0), (32768, 65536), (65536, 0), (45875, 19661)],
+                         ids=["always_full_move", "half_always", "never_moves", "go_demo_helper_rates"])
 def test_agent_mix_matches_oracle(g, mix):
-    """gvec_set_agent_mix: (0, 0) is the reference's random opponent (always a full move over the legal ones)."""
+    """gvec_set_agent_mix; (45875, 19661) are the rates of game.GenerateRandomActions (demo_helpers.go:20,44)."""
     B, w, h, p = 128, 12, 12, 3
     army, owner, typ, ww, hh, pp = H.gen_boards(77, [(w, h, p)] * B, w, h)
     eng = g.VecEngine(B, w, h, p)
