@@ -614,15 +614,31 @@ struct Board {
   // SERIALIZER = false: Engine.GetLegalActionMask, d = 0 up, 1 right, 2 down, 3 left (H10).
   // SERIALIZER = true : Serializer.GenerateActionMask (internal/experience/serializer.go:112-176):
   //   board owner (not the list), army >= 2, no Alive check, d = 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
+  // The player-independent half of the mask, laid out like a mask row: lane j (+64k) holds, for
+  // direction plane d = j / fd, the dword j % fd of "the d-neighbour is on the board and not a
+  // mountain".  Depends on the type planes and the geometry only: constant for the life of a board.
   template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
-    uint32_t gt1 = 0u;  // army > 1 as a flat plane
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
+  __device__ __forceinline__ void legal_targets(uint32_t (&okp)[MPASS], int fd) const {
     const uint32_t notm = ~mtn & valid;  // in-board, not a mountain (Validate :58-64,:96-98)
     const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);                  // target y-1 / y+1
     const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;  // target x+1 / x-1
     const uint32_t ok1 = SERIALIZER ? ok_dn : ok_rt, ok2 = SERIALIZER ? ok_lf : ok_dn, ok3 = SERIALIZER ? ok_rt : ok_lf;
+#pragma unroll
+    for (int k = 0; k < MPASS; ++k) {
+      const int j = lane_id() + 64 * k;
+      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
+      const int addr = (j - d * fd) << 2;  // flat lane j mod fd
+      // cross-lane reads: all unconditional
+      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
+      const uint32_t g = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
+      okp[k] = (j < 4 * fd) ? g : 0u;
+    }
+  }
+  template <bool SERIALIZER = false>
+  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd, const uint32_t (&okp)[MPASS]) const {
+    uint32_t gt1 = 0u;  // army > 1 as a flat plane
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
     uint32_t src[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
@@ -634,14 +650,16 @@ struct Board {
     for (int k = 0; k < MPASS; ++k) {
       const int j = lane_id() + 64 * k;
       const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
-      const int addr = (j - d * fd) << 2;  // flat lane j mod fd
-      // cross-lane reads: all unconditional
-      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
-      uint32_t okp = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
-      okp = (j < 4 * fd) ? okp : 0u;
+      const int addr = (j - d * fd) << 2;
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) out[p][k] = bperm(addr, src[p]) & okp;
+      for (int p = 0; p < MAXP; ++p) out[p][k] = bperm(addr, src[p]) & okp[k];  // cross-lane: unconditional
     }
+  }
+  template <bool SERIALIZER = false>
+  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
+    uint32_t okp[MPASS];
+    legal_targets<SERIALIZER>(okp, fd);
+    legal_masks<SERIALIZER>(out, fd, okp);
   }
 
   // ---- internal/experience/rewards.go helpers ---------------------------------------------------

@@ -174,9 +174,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   const size_t army_dw = (size_t)NSLOT * 64;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, A.army + (size_t)env * army_dw, FD);
   const bool emit = (A.flags & KF_EMIT) != 0u;
-  uint32_t lm[MAXP][MPASS];
+  uint32_t lm[MAXP][MPASS], okp[MPASS];
   uint32_t err = 0u;
-  bool types_dirty = false, changed = true;
+  bool types_dirty = false, changed = true, okp_valid = false;
   if (b.hflags & HF_DONE) {
     if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
       redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
@@ -188,7 +188,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   } else {
     uint32_t alo = 0u, ahi = 0u;
     if constexpr (AGENT) {
-      load_masks<MAXP, NSLOT>(lm, A, env);
+      // The agent's input is recomputed from the board instead of read back from the mask buffer the
+      // previous launch wrote: the kernel sits on its HBM floor (scripts/microbench/copy_pattern.hip)
+      // with VALU time to spare, so ~75 vector instructions are cheaper than 832 bytes per env.
+      b.template legal_targets<false>(okp, FD);
+      okp_valid = true;
+      b.template legal_masks<false>(lm, FD, okp);
       agent_sample<MAXP, NSLOT>(b, lm, FD, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
       if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
     } else if (lane < A.pstride) {
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
-    b.template legal_masks<false>(lm, FD);
+    if (!okp_valid) b.template legal_targets<false>(okp, FD);  // re-dealt board, or actions came from the host
+    b.template legal_masks<false>(lm, FD, okp);
     store_masks<MAXP, NSLOT>(lm, A, env);
   }
 }
@@ -246,8 +252,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   int k = 0;
   // The hot inner loop plays turns while the game is live; the rare events (game over: re-deal from
   // the pool, or freeze) sit in the outer loop so they do not shape the inner loop's registers.
+  uint32_t okp[MPASS];
   for (;;) {
-    b.template legal_masks<false>(lm, A.fd);  // the masks of the CURRENT state: the agent's input, the output at the end
+    b.template legal_targets<false>(okp, A.fd);  // once per board: the type planes only change on a re-deal
+    b.template legal_masks<false>(lm, A.fd, okp);  // the masks of the CURRENT state: the agent's input, the output at the end
     while (k < A.turns && !(b.hflags & HF_DONE)) {
       uint32_t alo, ahi;
       agent_sample<MAXP, NSLOT>(b, lm, A.fd, ek, A, alo, ahi);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
       n_abort += aborted ? 1u : 0u;
       n_done += (b.hflags & HF_DONE) ? 1u : 0u;
       ++k;
-      b.template legal_masks<false>(lm, A.fd);
+      b.template legal_masks<false>(lm, A.fd, okp);
     }
     if (k >= A.turns) break;
     if (!can_redeal) {
