@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""How long the step kernel takes when every board is frozen (finished game, no auto-reset): it then loads and stores
+header, planes and armies and does no turn work - a quick in-situ check of the memory side of the kernel
+(the standalone version with every array is scripts/microbench/copy_pattern.hip).  Run on a GPU box."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import generalsreinforcementlearning_amd as g
 B=262144
 e = g.VecEngine(B, 20, 20, 4, auto_reset=False, stream=torch.cuda.current_stream().cuda_stream)

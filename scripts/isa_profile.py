@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of one kernel, bucketed by the source function each instruction was inlined from."""
 import re, subprocess, sys, collections, os
-kern = sys.argv[1] if len(sys.argv) > 1 else "_ZN4gvec11step_kernelILi4ELi7EEEvNS_8StepArgsE"
+kern = sys.argv[1] if len(sys.argv) > 1 else "_ZN4gvec11step_kernelILi4ELi7ELb1ELb1EEEvNS_8StepArgsE"
 src = "/root/repo/generalsreinforcementlearning_amd/csrc/gvec_kernels.hip"
 os.makedirs("/tmp/st2", exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-gline-tables-only", "-c", src, "-o", "/tmp/st2/k.o", "-save-temps"], cwd="/tmp/st2", check=True, capture_output=True)
