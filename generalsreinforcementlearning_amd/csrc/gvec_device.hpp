@@ -175,8 +175,9 @@ struct Board {
     const int left = N - t0;
     valid = (lane_id() >= 32 || left <= 0) ? 0u : (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
     const uint32_t pat = kColumnPattern[W];  // bits at multiples of W below 32 (one scalar load)
-    const int q = (t0 * recipW) >> 16;  // t0 / W, exact for t0 < 1024
-    const int x0 = t0 - q * W;          // column of this lane's first tile
+    // 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); t0 < 2048, recipW <= 65536, W <= 32
+    const int q = (int)(__umul24((uint32_t)t0, (uint32_t)recipW) >> 16);  // t0 / W, exact for t0 < 1024
+    const int x0 = t0 - (int)__umul24((uint32_t)q, (uint32_t)W);          // column of this lane's first tile
     const uint32_t col0 = pat << (x0 ? W - x0 : 0);
     ncol0 = ~col0;
     ncolL = ~__builtin_amdgcn_alignbit(from_next(col0), col0, 1);  // t is in the last column iff t+1 is in column 0
@@ -472,8 +473,8 @@ struct Board {
     code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;      // :67-69
     code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;  // :58-64
     v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
-    v.ft = fy * W + fx;
-    v.tt = ty * W + tx;
+    v.ft = __mul24(fy, W) + fx;  // |coordinates| < 128: full-rate 24-bit multiply
+    v.tt = __mul24(ty, W) + tx;
     return v;
   }
 

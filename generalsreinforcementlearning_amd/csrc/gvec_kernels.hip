@@ -74,7 +74,7 @@ __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
     t = (lane == p) ? tt : t;
     d = (lane == p) ? dd : d;
   }
-  const int y = (t * b.recipW) >> 16, x = t - y * b.W;
+  const int y = (int)(__umul24((uint32_t)t, (uint32_t)b.recipW) >> 16), x = t - (int)__umul24((uint32_t)y, (uint32_t)b.W);  // t < 1024
   const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
   const uint32_t lo = ((uint32_t)x & 0xFFu) | (((uint32_t)y & 0xFFu) << 8) | (((uint32_t)(x + dx) & 0xFFu) << 16) |
                       (((uint32_t)(y + dy) & 0xFFu) << 24);
