@@ -26,6 +26,7 @@ static void set_err(const char* fmt, ...) {
     hipError_t e__ = (expr);                                                           \
     if (e__ != hipSuccess) {                                                           \
       set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* reported: do not leave it for the next launch's error check */ \
       return GVEC_E_HIP;                                                               \
     }                                                                                  \
   } while (0)
@@ -210,6 +211,36 @@ int32_t ensure_device() {
   return GVEC_OK;
 }
 
+// device allocations of a new handle; on failure the caller destroys the handle (which frees what exists)
+int32_t allocate_handle(gvec_handle* h, const gvec_config* cfg) {
+  const size_t B = (size_t)cfg->num_envs;
+  HIPCHK(hipMalloc(&h->d_hdr, B * HDR_DW * 4));
+  HIPCHK(hipMalloc(&h->d_rows, B * h->row_dw * 4));
+  HIPCHK(hipMalloc(&h->d_army, B * h->army_dw * 4));
+  HIPCHK(hipMalloc(&h->d_legal, B * h->maxp * h->mask_bytes));
+  HIPCHK(hipMalloc(&h->d_actions, B * h->maxp * sizeof(gvec_action)));
+  HIPCHK(hipMalloc(&h->d_err, B * 4));
+  HIPCHK(hipMalloc(&h->d_status, 16));
+  HIPCHK(hipMalloc(&h->d_counters, 6 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(h->d_rows, 0, B * h->row_dw * 4));
+  HIPCHK(hipMemset(h->d_army, 0, B * h->army_dw * 4));
+  HIPCHK(hipMemset(h->d_legal, 0, B * h->maxp * h->mask_bytes));
+  HIPCHK(hipMemset(h->d_actions, 0, B * h->maxp * sizeof(gvec_action)));
+  HIPCHK(hipMemset(h->d_err, 0, B * 4));
+  HIPCHK(hipMemset(h->d_status, 0, 16));
+  {  // every slot starts as a finished 1x1 one-player game, so any kernel is safe before gvec_reset
+    std::vector<uint32_t> hdr(B * HDR_DW, 0u);
+    for (size_t e = 0; e < B; ++e) {
+      uint32_t* x = &hdr[e * HDR_DW];
+      x[H_DIMS] = 1u | (1u << 8) | (1u << 16) | ((HF_DONE | (cfg->fog_of_war ? HF_FOG : 0u)) << 24);
+      x[H_RECIPW] = 65536u;
+      for (int p = 0; p < 8; ++p) x[H_GIDX + p] = 0xFFFFFFFFu;
+    }
+    HIPCHK(hipMemcpy(h->d_hdr, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+  }
+  return GVEC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -267,30 +298,12 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   h->mask_bytes = 16 * h->fd;  // four direction bit-planes of fd dwords per player
   h->mask_dw = h->mask_bytes / 4;
   h->stream = nullptr;
-  const size_t B = (size_t)cfg->num_envs;
-  HIPCHK(hipMalloc(&h->d_hdr, B * HDR_DW * 4));
-  HIPCHK(hipMalloc(&h->d_rows, B * h->row_dw * 4));
-  HIPCHK(hipMalloc(&h->d_army, B * h->army_dw * 4));
-  HIPCHK(hipMalloc(&h->d_legal, B * h->maxp * h->mask_bytes));
-  HIPCHK(hipMalloc(&h->d_actions, B * h->maxp * sizeof(gvec_action)));
-  HIPCHK(hipMalloc(&h->d_err, B * 4));
-  HIPCHK(hipMalloc(&h->d_status, 16));
-  HIPCHK(hipMalloc(&h->d_counters, 6 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(h->d_rows, 0, B * h->row_dw * 4));
-  HIPCHK(hipMemset(h->d_army, 0, B * h->army_dw * 4));
-  HIPCHK(hipMemset(h->d_legal, 0, B * h->maxp * h->mask_bytes));
-  HIPCHK(hipMemset(h->d_actions, 0, B * h->maxp * sizeof(gvec_action)));
-  HIPCHK(hipMemset(h->d_err, 0, B * 4));
-  HIPCHK(hipMemset(h->d_status, 0, 16));
-  {  // every slot starts as a finished 1x1 one-player game, so any kernel is safe before gvec_reset
-    std::vector<uint32_t> hdr(B * HDR_DW, 0u);
-    for (size_t e = 0; e < B; ++e) {
-      uint32_t* x = &hdr[e * HDR_DW];
-      x[H_DIMS] = 1u | (1u << 8) | (1u << 16) | ((HF_DONE | (cfg->fog_of_war ? HF_FOG : 0u)) << 24);
-      x[H_RECIPW] = 65536u;
-      for (int p = 0; p < 8; ++p) x[H_GIDX + p] = 0xFFFFFFFFu;
+  {
+    const int32_t rc = allocate_handle(h, cfg);
+    if (rc != GVEC_OK) {
+      (void)gvec_destroy(h);
+      return rc;
     }
-    HIPCHK(hipMemcpy(h->d_hdr, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
   }
   h->legal_valid = true;
   *out = h;

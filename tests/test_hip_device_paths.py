@@ -146,3 +146,19 @@ def test_agent_mix_matches_oracle(g, mix):
     H.assert_states_equal(eng.game_state(), ora.read_state(), f"agent mix {mix}")
     with pytest.raises(g.GvecError):
         eng.set_agent_mix(-1, 0)
+
+
+@pytest.mark.gpu
+def test_failed_creation_reports_and_releases(g):
+    """A handle that cannot be allocated returns a HIP error (no partial handle, nothing left allocated)."""
+    import torch
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        with pytest.raises(g.GvecError) as ei:
+            g.VecEngine(400_000_000, 32, 32, 8)   # ~ 5 TB of board state
+        assert ei.value.code == -3  # GVEC_E_HIP
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (256 << 20)
+    eng = g.VecEngine(4, 5, 5, 2)   # the library is still usable
+    eng.reset_generated(1)
+    assert eng.game_state()["turn"].tolist() == [0, 0, 0, 0]
