@@ -108,7 +108,8 @@ int32_t check_status(gvec_handle* h, const char* what) {
     int32_t zero = 0;
     HIPCHK(hipMemcpyAsync(h->d_status, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    set_err("%s: input violates the board contract (code %d: sizes within max_*, owner in [-1, players))", what, st);
+    set_err("%s: input rejected on the device (code %d; -5: board contract - sizes within max_*, owner in [-1, players); "
+            "-4: env id out of range)", what, st);
     return st;
   }
   return GVEC_OK;
@@ -163,7 +164,7 @@ int32_t copy_out(gvec_handle* h, const DevBuf& buf, T* dst, size_t count, int32_
   } while (0)
 
 int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* army, const int32_t* env_ids_dev, int dst_begin,
-                      int n, const gvec_state_view* v /*device pointers*/, bool fresh, bool init) {
+                      int n, int dst_envs, const gvec_state_view* v /*device pointers*/, bool fresh, bool init) {
   ImportArgs a;
   memset(&a, 0, sizeof a);
   a.hdr = hdr;
@@ -172,6 +173,7 @@ int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* ar
   a.env_ids = env_ids_dev;
   a.dst_begin = dst_begin;
   a.n = n;
+  a.dst_envs = dst_envs;
   a.s_army = v->army;
   a.s_owner = v->owner;
   a.s_type = v->type;
@@ -359,7 +361,7 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
   RET_IF(stage_in(h, b_w, width, (size_t)n, mem, (const int32_t**)&v.width));
   RET_IF(stage_in(h, b_h, height, (size_t)n, mem, (const int32_t**)&v.height));
   RET_IF(stage_in(h, b_p, players, (size_t)n, mem, (const int32_t**)&v.players));
-  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, ids, 0, n, &v, true, true));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, ids, 0, n, h->cfg.num_envs, &v, true, true));
   RET_IF(check_status(h, "gvec_reset"));
   return refresh_legal(h);
 }
@@ -412,7 +414,7 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int3
     v.width = m.width;
     v.height = m.height;
     v.players = m.players;
-    RET_IF(import_planes(h, hdr, rows, army, nullptr, first, n, &v, true, true));
+    RET_IF(import_planes(h, hdr, rows, army, nullptr, first, n, count, &v, true, true));
     HIPCHK(hipStreamSynchronize(h->stream));  // staging is reused by the next chunk
   }
   return check_status(h, "map generation");
@@ -591,7 +593,7 @@ int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gve
   RET_IF(stage_in(h, b[9], view->alive, np, mem, (const uint8_t**)&v.alive));
   RET_IF(stage_in(h, b[10], view->army_count, np, mem, (const int32_t**)&v.army_count));
   RET_IF(stage_in(h, b[11], view->general_idx, np, mem, (const int32_t**)&v.general_idx));
-  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, nullptr, env_begin, n, &v, false, false));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, nullptr, env_begin, n, h->cfg.num_envs, &v, false, false));
   RET_IF(check_status(h, "gvec_write_state"));
   return refresh_legal(h);
 }

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
   const int env = A.env_ids ? uni(A.env_ids[i]) : A.dst_begin + i;
+  if (env < 0 || env >= A.dst_envs) {  // ids handed over in device memory were not seen by the host
+    if (lane == 0) atomicExch(A.status, GVEC_E_RANGE);
+    return;
+  }
   uint32_t* hdr = A.hdr + (size_t)env * HDR_DW;
   uint32_t* rows = A.rows + (size_t)env * A.row_dw;
   int32_t* army = A.army + (size_t)env * NSLOT * 64;

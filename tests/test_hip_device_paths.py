@@ -162,3 +162,29 @@ def test_failed_creation_reports_and_releases(g):
     eng = g.VecEngine(4, 5, 5, 2)   # the library is still usable
     eng.reset_generated(1)
     assert eng.game_state()["turn"].tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_device_side_env_ids_are_range_checked(g):
+    """env_ids handed over in DEVICE memory cannot be checked by the host: the import kernel rejects ids outside
+    [0, num_envs) instead of writing out of bounds, and the valid envs of the call are still reset."""
+    import torch
+    from generalsreinforcementlearning_amd._lib import check
+    B, w, h, P = 16, 8, 8, 2
+    army, owner, typ, ws, hs, ps = H.gen_boards(21, [(w, h, P)] * B, w, h)
+    eng = g.VecEngine(B, w, h, P, stream=torch.cuda.current_stream().cuda_stream)
+    eng.reset(army, owner, typ, ws, hs, ps)
+    eng.rollout(7, 3, 0)
+    assert (eng.game_state()["turn"] == 7).all()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    n = 3
+    ids = t(np.array([2, B + 5, 9], np.int32))          # the middle id is out of range
+    d = [t(army[:n]), t(owner[:n]), t(typ[:n]), t(ws[:n]), t(hs[:n]), t(ps[:n])]
+    rc = eng.L.gvec_reset(eng.h, ids.data_ptr(), n, *[x.data_ptr() for x in d], 1)
+    assert rc == -4  # GVEC_E_RANGE
+    assert b"env id out of range" in eng.L.gvec_last_error()
+    turn = eng.game_state()["turn"]
+    assert turn[2] == 0 and turn[9] == 0 and (np.delete(turn, [2, 9]) == 7).all()
+    ids_ok = t(np.array([1, 4, 15], np.int32))
+    check(eng.L.gvec_reset(eng.h, ids_ok.data_ptr(), n, *[x.data_ptr() for x in d], 1), "gvec_reset")
+    assert (eng.game_state()["turn"][[1, 4, 15]] == 0).all()
