@@ -1,12 +1,25 @@
 // gvec_kernels.hip — HIP kernels for gfx950 (MI355X).  One wavefront per board; see
 // gvec_device.hpp for the register layout and the reference citations.
 #include "gvec_launch.hpp"
+#include "gvec_packed.hpp"
 
 #include <type_traits>
 
 namespace gvec {
 
 constexpr int WAVES_PER_BLOCK = 4;
+
+// The per-turn step kernel and the query kernels hold a board of four or more players as PBoard (players
+// packed into register rows, gvec_packed.hpp): one-process A/B against Board, per turn: 20x20 4P +1 %,
+// 25x25 4P +8 %, 32x32 8P +15 % (no spills left), 15x15 2P -1.6 % (nothing to pack: stays on Board).
+// The fused rollout kernel stays on Board (same VALU count either way, 3 % faster unpacked).
+// -DGVEC_PACKED=0 builds everything on Board for A/B runs.
+#ifndef GVEC_PACKED
+#define GVEC_PACKED 1
+#endif
+constexpr bool packed_variant(int maxp) { return GVEC_PACKED != 0 && maxp >= 4; }
+template <int MAXP, int NSLOT>
+using HotBoard = std::conditional_t<packed_variant(MAXP), PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
 
 // =========================================================================================
 // random agent (DESIGN.md "Synthetic inputs"; mirrored by oracle agent_env)
@@ -23,8 +36,8 @@ __device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
 // All hashing / coordinate arithmetic runs on lanes (lane p = player p); only the choice of the
 // k-th legal move needs a wave-wide scan per player.  "k-th" counts the set bits of the player's packed
 // mask row in storage order: direction plane 0 tile 0.., then plane 1, ... (fd = dwords per plane).
-template <int MAXP, int NSLOT>
-__device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
+template <int MAXP, int NSLOT, typename BT>
+__device__ __forceinline__ void agent_sample(const BT& b,
                                              const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], int fd, uint32_t ek,
                                              const StepArgs& A, uint32_t& alo, uint32_t& ahi) {
   const int invalid_permille = A.invalid_permille;
@@ -85,9 +98,8 @@ __device__ __forceinline__ void agent_sample(const Board<MAXP, NSLOT>& b,
 // =========================================================================================
 // step / rollout kernel: `turns` engine turns per launch for one board per wavefront
 // =========================================================================================
-template <int MAXP, int NSLOT>
-__device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t* hdr, const uint32_t* rows,
-                                           const int32_t* army, int fd) {
+template <typename BT>
+__device__ __forceinline__ void load_board(BT& b, const uint32_t* hdr, const uint32_t* rows, const int32_t* army, int fd) {
   b.load_hdr(hdr);
   b.geometry();
   b.load_army(army);
@@ -95,8 +107,8 @@ __device__ __forceinline__ void load_board(Board<MAXP, NSLOT>& b, const uint32_t
 }
 
 // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
-template <int MAXP, int NSLOT>
-__device__ __forceinline__ void redeal(Board<MAXP, NSLOT>& b, const StepArgs& A, int env, int fd, int row_dw) {
+template <int MAXP, int NSLOT, typename BT>
+__device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd, int row_dw) {
   const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
   const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
@@ -141,7 +153,9 @@ __device__ __forceinline__ void store_masks(const Masks<MAXP, NSLOT>& lm, const 
 // spill, which is worth 7 % over 7 waves (one-process A/B): the turn is a long dependent chain of
 // short cross-lane operations, and the VALU only stays fed with every wave slot occupied.
 constexpr int step_waves(int maxp, int nslot) {
-  const int state = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1);
+  const int ppr = (nslot <= 7) ? 4 : 2;  // PBoard: players per plane register
+  const int plane_regs = packed_variant(maxp) ? 3 * ((maxp + ppr - 1) / ppr) + 5 : 3 * maxp + 5;
+  const int state = plane_regs + nslot + maxp * ((nslot > 8) ? 2 : 1);
   const int need = state + (state + 32 <= 64 ? 32 : 40);  // larger variants: keep spills out of the turn
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
   constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];  // per wave: the action phase's army copy
-  using B = Board<MAXP, NSLOT>;
+  using B = HotBoard<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
@@ -236,7 +250,7 @@ constexpr int rollout_waves(int maxp, int nslot) {
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
-  using B = Board<MAXP, NSLOT>;
+  using B = Board<MAXP, NSLOT>;  // measured: the fused loop is 3 % faster on the unpacked registers (same VALU count, shorter chains)
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
 // MODE 0: Engine.GetLegalActionMask   1: random-agent actions   2: Serializer.GenerateActionMask
 template <int MAXP, int NSLOT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A) {
-  using B = Board<MAXP, NSLOT>;
+  using B = HotBoard<MAXP, NSLOT>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);

@@ -1,0 +1,545 @@
+// gvec_packed.hpp — the hot kernels' register layout: per-player planes packed into register ROWS.
+//
+// Board (gvec_device.hpp) keeps one register per (plane kind, player): 12 registers of which a 20x20
+// board uses 13 of 64 lanes each.  PBoard lays the players of one kind side by side in one register:
+//
+//     row r of register k (lanes r*ROWL .. r*ROWL + ROWL-1)  =  player k*PPR + r
+//     lane column c = lane % ROWL                            =  dword c of the bit string (tiles 32c..32c+31)
+//
+// with ROWL = 16 (PPR = 4 players per register) for boards up to 448 tiles and ROWL = 32 (PPR = 2) above.
+// The planes every player shares (chg, vch, gen, city, mtn) and the geometry masks are REPLICATED in
+// every row, so a packed plane combines with them lane by lane.  Every per-player flat operation of the
+// turn (fog dilations, list refresh, mask sources) now runs once per register instead of once per
+// player.  The wave-wide bit-string shifts stay correct because the last lanes of every row hold no
+// tiles (fd <= 14 of 16, fd <= 32 of 32 - the one full case is masked explicitly).
+//
+// HBM layout, tile domain (armies), header and the semantics are exactly Board's; the cold kernels
+// (import / export / experience) keep using Board.  Every routine cites the Go function it reproduces,
+// like its counterpart in gvec_device.hpp.
+#pragma once
+#include "gvec_device.hpp"
+
+namespace gvec {
+
+template <int MAXP, int NSLOT>
+struct PBoard {
+  using PL = Planes<MAXP>;
+  static constexpr int MPASS = (NSLOT > 8) ? 2 : 1;
+  static constexpr int PPR = (NSLOT <= 7) ? 4 : 2;    // players per plane register
+  static constexpr int ROWL = 64 / PPR;               // lanes per row
+  static constexpr int NR = (MAXP + PPR - 1) / PPR;   // registers per plane kind
+  static constexpr bool FULL_ROWS = (2 * NSLOT >= ROWL);  // a plane can fill its row: shifts must not cross rows
+
+  uint32_t own[NR], lst[NR], vis[NR];         // packed: row r of register k = player k*PPR + r
+  uint32_t chg, vch, gen, city, mtn;          // replicated in every row
+  uint32_t valid, ncol0, ncolL;               // replicated geometry masks (see Board)
+  uint32_t rowbit[NR];                        // 1 << (the player this lane holds in register k): set by geometry()
+  int32_t army[NSLOT];                        // tile domain, as in Board
+  uint32_t hv;
+  int32_t* larmy;
+  int W, H, P, N, turn, recipW;
+  uint32_t alive, hflags;
+
+  static __device__ __forceinline__ int col() { return lane_id() & (ROWL - 1); }
+  static __device__ __forceinline__ int row() { return lane_id() / ROWL; }
+  // the player whose bits this lane holds in register k
+  static __device__ __forceinline__ int lane_player(int k) { return k * PPR + row(); }
+  // bit (k*PPR + row) of a per-player bit set: "the property holds for this lane's player"
+  __device__ __forceinline__ bool lane_flag(uint32_t bits, int k) const { return (bits & rowbit[k]) != 0u; }
+  static __device__ __forceinline__ bool in_row_of(int p) { return row() == (p % PPR); }
+
+  // ---- geometry (Board::geometry with the lane's column) ---------------------------------------
+  __device__ __forceinline__ void geometry() {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rowbit[k] = 1u << lane_player(k);
+    const int t0 = 32 * col();
+    const int left = N - t0;
+    valid = (left <= 0) ? 0u : (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
+    const uint32_t pat = kColumnPattern[W];
+    const int q = (int)(__umul24((uint32_t)t0, (uint32_t)recipW) >> 16);
+    const int x0 = t0 - (int)__umul24((uint32_t)q, (uint32_t)W);
+    const uint32_t col0 = pat << (x0 ? W - x0 : 0);
+    ncol0 = ~col0;
+    ncolL = ~__builtin_amdgcn_alignbit(next_lane(col0), col0, 1);
+  }
+
+  // ---- bit-string shifts inside a row -------------------------------------------------------------
+  static __device__ __forceinline__ uint32_t prev_lane(uint32_t m) {
+    const uint32_t v = from_prev(m);
+    if constexpr (FULL_ROWS) return (col() == 0) ? 0u : v;
+    return v;  // the previous row's last lanes hold no tiles
+  }
+  static __device__ __forceinline__ uint32_t next_lane(uint32_t m) {
+    const uint32_t v = from_next(m);
+    if constexpr (FULL_ROWS) return (col() == ROWL - 1) ? 0u : v;
+    return v;  // lands in a lane beyond the board (masked by `valid`) or reads a zero lane
+  }
+  __device__ __forceinline__ uint32_t up1(uint32_t m) const { return __builtin_amdgcn_alignbit(m, prev_lane(m), 31); }
+  __device__ __forceinline__ uint32_t dn1(uint32_t m) const { return __builtin_amdgcn_alignbit(next_lane(m), m, 1); }
+  __device__ __forceinline__ uint32_t upW(uint32_t m) const {
+    return __builtin_amdgcn_alignbit(m, prev_lane(m), (uint32_t)(32 - W) & 31u);
+  }
+  __device__ __forceinline__ uint32_t dnW(uint32_t m) const { return (uint32_t)((((uint64_t)next_lane(m) << 32) | (uint64_t)m) >> W); }
+  __device__ __forceinline__ uint32_t dil_h(uint32_t m) const { return m | (up1(m) & ncol0) | (dn1(m) & ncolL); }
+  __device__ __forceinline__ uint32_t dil_v(uint32_t m) const { return (m | upW(m) | dnW(m)) & valid; }
+  __device__ __forceinline__ uint32_t dil3(uint32_t m) const { return dil_v(dil_h(m)); }
+
+  // OR of the rows of a packed plane, replicated into every row
+  static __device__ __forceinline__ uint32_t or_rows(uint32_t x) {
+    if constexpr (PPR == 4) x |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);  // lane ^ 16
+    x |= bperm((lane_id() ^ 32) << 2, x);
+    return x;
+  }
+  // player p's plane out of its packed register, replicated into every row (cross-lane: uniform flow only)
+  __device__ __forceinline__ uint32_t unpack(const uint32_t (&reg)[NR], int p) const {
+    uint32_t r = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t g = bperm((((p % PPR) * ROWL) + col()) << 2, reg[k]);
+      r = (k == p / PPR) ? g : r;
+    }
+    return r;
+  }
+
+  // ---- header (Board's) ---------------------------------------------------------------------------
+  __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
+    const int lane = lane_id();
+    hv = (lane < HDR_DW) ? hdr_env[lane] : 0u;
+    turn = (int)rdlane(hv, H_TURN);
+    const uint32_t dims = rdlane(hv, H_DIMS);
+    W = (int)(dims & 0xFFu);
+    H = (int)((dims >> 8) & 0xFFu);
+    P = (int)((dims >> 16) & 0xFFu);
+    hflags = dims >> 24;
+    N = W * H;
+    alive = rdlane(hv, H_STATUS) & 0xFFu;
+    recipW = (int)rdlane(hv, H_RECIPW);
+  }
+  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (lane_id() == k) ? v : hv; }
+  __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
+  __device__ __forceinline__ void store_hdr(uint32_t* hdr_env, uint32_t last_err) {
+    hdr_set(H_TURN, (uint32_t)turn);
+    hdr_set(H_DIMS, (uint32_t)W | ((uint32_t)H << 8) | ((uint32_t)P << 16) | (hflags << 24));
+    hdr_set(H_STATUS, alive | (last_err << 16));
+    hdr_set(H_RECIPW, (uint32_t)recipW);
+    if (lane_id() < HDR_DW) hdr_env[lane_id()] = hv;
+  }
+
+  // ---- planes: one load per packed register (PPR planes at once), shared planes replicated ------------
+  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd) {
+    const bool in = col() < fd;
+    const uint32_t* gp = rows_env + (in ? row() * fd + col() : 0);  // packed: plane (base + row), dword col
+    const uint32_t* gs = rows_env + (in ? col() : 0);               // shared: every row reads the same dwords
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const bool on = in && (k * PPR + row() < MAXP);
+      const uint32_t a = gp[(PL::OWN + k * PPR) * fd], b = gp[(PL::LST + k * PPR) * fd], c = gp[(PL::VIS + k * PPR) * fd];
+      own[k] = on ? a : 0u;
+      lst[k] = on ? b : 0u;
+      vis[k] = on ? c : 0u;
+    }
+    const uint32_t a = gs[PL::CHG * fd], b = gs[PL::VCH * fd], c = gs[PL::GEN * fd], d = gs[PL::CITY * fd], e = gs[PL::MTN * fd];
+    chg = in ? a : 0u;
+    vch = in ? b : 0u;
+    gen = in ? c : 0u;
+    city = in ? d : 0u;
+    mtn = in ? e : 0u;
+  }
+  __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
+    const bool in = col() < fd;
+    uint32_t* gp = rows_env + row() * fd + col();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      if (in && (k * PPR + row() < MAXP)) {
+        gp[(PL::OWN + k * PPR) * fd] = own[k];
+        gp[(PL::LST + k * PPR) * fd] = lst[k];
+        gp[(PL::VIS + k * PPR) * fd] = vis[k];
+      }
+    }
+    const int lane = lane_id();
+    if (lane < fd) {  // lanes 0..fd-1 are row 0, columns 0..fd-1 (fd <= ROWL)
+      rows_env[PL::CHG * fd + lane] = chg;
+      rows_env[PL::VCH * fd + lane] = vch;
+      if (with_types) {
+        rows_env[PL::GEN * fd + lane] = gen;
+        rows_env[PL::CITY * fd + lane] = city;
+      }
+    }
+    if (with_types && lane < row_dw - PL::MTN * fd) rows_env[PL::MTN * fd + lane] = (lane < fd) ? mtn : 0u;  // + the block's padding
+  }
+  __device__ __forceinline__ void load_army(const int32_t* army_env) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) army[s] = army_env[64 * s + lane_id()];
+  }
+  __device__ __forceinline__ void store_army(int32_t* army_env) const {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) army_env[64 * s + lane_id()] = army[s];
+  }
+
+  // ---- LDS army shadow of the action phase (Board's) -----------------------------------------------
+  __device__ __forceinline__ void army_to_lds() {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) larmy[64 * s + lane_id()] = army[s];
+    wave_lds_fence();
+  }
+  __device__ __forceinline__ void army_from_lds() {
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) army[s] = larmy[64 * s + lane_id()];
+  }
+  __device__ __forceinline__ int army_get(int t) const { return uni(larmy[t]); }
+  __device__ __forceinline__ void army_set(int t, int val) {
+    if (lane_id() == 0) larmy[t] = val;
+  }
+
+  // ---- single tiles ------------------------------------------------------------------------------------
+  __device__ __forceinline__ bool bit_at(uint32_t shared_plane, int t) const { return (rdlane(shared_plane, t >> 5) >> (t & 31)) & 1u; }
+  __device__ __forceinline__ bool bit_at_p(const uint32_t (&reg)[NR], int p, int t) const {
+    uint32_t w = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t r = rdlane(reg[k], (p % PPR) * ROWL + (t >> 5));
+      w = (k == p / PPR) ? r : w;
+    }
+    return (w >> (t & 31)) & 1u;
+  }
+  // the single bit of tile t, in every row
+  __device__ __forceinline__ uint32_t tile_bit(int t) const { return (col() == (t >> 5)) ? (1u << (t & 31)) : 0u; }
+
+  // ---- flat <-> tile domain ---------------------------------------------------------------------------
+  // tile 64s+l is bit l&31 of dword 2s + (l>>5); row 0 of a replicated plane, row (p % PPR) of a packed one
+  __device__ __forceinline__ int32_t gather_mask(uint32_t plane, int s, int row_base = 0) const {
+    const int lane = lane_id();
+    return __builtin_amdgcn_sbfe((int32_t)bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
+  }
+  __device__ __forceinline__ void scatter(uint32_t& plane, unsigned long long ballot, int s) const {  // into every row
+    plane = (col() == 2 * s) ? (uint32_t)ballot : plane;
+    plane = (col() == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
+  }
+  // popcount of a replicated plane (row 0 only)
+  __device__ __forceinline__ int count_shared(uint32_t plane) const {
+    return (int)wave_sum((lane_id() < ROWL) ? (uint32_t)__builtin_popcount(plane) : 0u);
+  }
+
+  // ---- Engine.updateFogOfWarOptimized (visibility_optimized.go:16-97) ---------------------------------
+  __device__ __forceinline__ void update_fog() {
+    if (!(hflags & HF_FOG)) return;  // :17-19
+    const int nv = count_shared(vch);
+    if (turn == 0 || nv > N / 10) {  // :22-26 full: clear, then 3x3 around every listed tile of alive players (:33-53)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const uint32_t d = dil3(lst[k]);  // all players of the register at once
+        vis[k] = lane_flag(alive, k) ? d : 0u;
+      }
+      return;
+    }
+    if (nv == 0) return;
+    // :56-97 affected = board owners within 5x5 of V (:100-116); clear all players in 3x3 of V
+    // (:132-150); re-light affected, alive players from their lists (:85-94)
+    const uint32_t near3 = dil3(vch), near5 = dil3(near3), clr = ~near3;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const unsigned long long hit = __builtin_amdgcn_ballot_w64((own[k] & near5) != 0u);
+      uint32_t relight = 0u;  // per-player bit set, wave-uniform
+#pragma unroll
+      for (int r = 0; r < PPR; ++r) {
+        const unsigned long long rowbits = (ROWL == 32) ? 0xFFFFFFFFull : 0xFFFFull;
+        relight |= ((hit >> (r * ROWL)) & rowbits) ? (1u << (k * PPR + r)) : 0u;
+      }
+      relight &= alive;
+      const uint32_t d = dil3(lst[k]);
+      vis[k] = (vis[k] & clr) | (lane_flag(relight, k) ? d : 0u);
+    }
+  }
+
+  // ---- one reduction tree for MAXP accumulators (Board::multi_sum) ---------------------------------
+  __device__ __forceinline__ uint32_t multi_sum(const int32_t (&acc)[MAXP]) const {
+    static_assert(MAXP == 2 || MAXP == 4 || MAXP == 8, "fold levels are written for 2, 4 or 8 players");
+    static_assert(H_ARMYCNT == 4, "the final row_shl assumes header lanes 4..4+MAXP-1");
+    const int lane = lane_id();
+    uint32_t m[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) m[p] = (uint32_t)acc[p];
+    {
+      const bool hi = (lane & 1) != 0;
+#pragma unroll
+      for (int i = 0; i < MAXP / 2; ++i) {
+        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
+        m[i] = keep + dpp0<0xB1>(give);
+      }
+    }
+    if constexpr (MAXP >= 4) {
+      const bool hi = (lane & 2) != 0;
+#pragma unroll
+      for (int i = 0; i < MAXP / 4; ++i) {
+        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
+        m[i] = keep + dpp0<0x4E>(give);
+      }
+    }
+    if constexpr (MAXP >= 8) {
+      const bool hi = (lane & 4) != 0;
+      const uint32_t keep = hi ? m[1] : m[0], give = hi ? m[0] : m[1];
+      m[0] = keep + dpp0<0x124>(give);
+    }
+    uint32_t r = m[0];
+    if constexpr (MAXP <= 2) r += dpp0<0x112>(r);
+    if constexpr (MAXP <= 4) r += dpp0<0x114>(r);
+    r += dpp0<0x118>(r);
+    r += (uint32_t)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);
+    r += bperm((lane ^ 32) << 2, r);
+    return dpp0<0x100 + 12 - MAXP>(r);
+  }
+
+  // ---- Engine.updatePlayerStats (stats.go:8-144) ------------------------------------------------------
+  __device__ __forceinline__ void update_stats() {
+    const int nc = count_shared(chg);
+    if (nc == 0 && turn > 0) return;             // :10-14
+    const bool full = turn == 0 || nc > N / 5;  // :20-21
+#pragma unroll
+    for (int k = 0; k < NR; ++k) lst[k] = full ? own[k] : (own[k] & (lst[k] | chg));  // :33-49 / :90-130
+    int32_t acc[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) acc[p] = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
+    }
+    {
+      const int lane = lane_id();
+      const uint32_t tot = multi_sum(acc);
+      hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
+    }
+    alive = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t g = lst[k] & gen;
+      const unsigned long long nz = __builtin_amdgcn_ballot_w64(g != 0u);
+#pragma unroll
+      for (int r = 0; r < PPR; ++r) {
+        const int p = k * PPR + r;
+        if (p < MAXP) {
+          // GeneralIdx: the highest listed general tile (see Board::update_stats)
+          const unsigned long long rowbits = (ROWL == 32) ? 0xFFFFFFFFull : 0xFFFFull;
+          const uint32_t dw = (uint32_t)((nz >> (r * ROWL)) & rowbits);
+          int gi = -1;
+          if (dw) {
+            const int i = 31 - __builtin_clz(dw);
+            gi = 32 * i + (31 - __builtin_clz(rdlane(g, r * ROWL + i)));
+          }
+          hdr_set(H_GIDX + p, (uint32_t)gi);
+          alive |= (gi >= 0) ? (1u << p) : 0u;  // :52-54 / :133-135
+        }
+      }
+    }
+  }
+
+  // ---- ProductionManager.ProcessTurnProduction (production_manager.go:26-101) ------------------------
+  __device__ __forceinline__ void production(int pg, int pc, int pn, int interval) {
+    const bool grow = (turn % interval) == 0;  // :27
+    uint32_t listed_alive = 0u;                // :39-45: lists of alive players, owner NOT re-checked (H7)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) listed_alive |= lane_flag(alive, k) ? lst[k] : 0u;
+    listed_alive = or_rows(listed_alive);
+    const uint32_t normal = ~(gen | city | mtn) & valid;
+    const uint32_t mg = (pg > 0) ? (listed_alive & gen) : 0u;
+    const uint32_t mc = (pc > 0) ? (listed_alive & city) : 0u;
+    const uint32_t mn = (grow && pn > 0) ? (listed_alive & normal) : 0u;
+    chg |= mg | mc | mn;  // :59-61 (prod > 0 only)
+    const int an = (grow && pn > 0) ? pn : pc;
+    if (pg == pc && pc == an) {
+      const uint32_t m = mg | mc | mn;
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) army[s] += pg & gather_mask(m, s);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) army[s] += (pg & gather_mask(mg, s)) + (pc & gather_mask(mc, s)) + (pn & gather_mask(mn, s));
+    }
+  }
+
+  // ---- WinConditionChecker.CheckGameOver (rules/win_conditions.go:21-57) ---------------------------
+  __device__ __forceinline__ void check_game_over() {
+    const int na = __builtin_popcount(alive);
+    const bool over = (P > 1) ? (na <= 1) : (na == 0);
+    hflags = over ? (hflags | HF_DONE) : (hflags & ~HF_DONE);
+  }
+
+  // ---- the action phase (Board's, on packed ownership) -------------------------------------------------
+  struct ActVec {
+    uint32_t meta;  // bits 0-3 static Validate code, bit 4 present (non-nil), bit 5 half
+    int ft, tt;     // y*W + x of source / target
+  };
+  __device__ __forceinline__ ActVec prevalidate(uint32_t alo, uint32_t ahi) const {
+    ActVec v;
+    const int fx = (int)(int8_t)(alo & 0xFFu), fy = (int)(int8_t)((alo >> 8) & 0xFFu);
+    const int tx = (int)(int8_t)((alo >> 16) & 0xFFu), ty = (int)(int8_t)(alo >> 24);
+    const bool inb = fx >= 0 && fx < W && fy >= 0 && fy < H && tx >= 0 && tx < W && ty >= 0 && ty < H;
+    const int dx = fx - tx, dy = fy - ty;
+    const int md = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
+    uint32_t code = 0u;
+    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;      // action.go:72-76
+    code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;      // :67-69
+    code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;  // :58-64
+    v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
+    v.ft = __mul24(fy, W) + fx;
+    v.tt = __mul24(ty, W) + tx;
+    return v;
+  }
+
+  template <int PID>
+  __device__ __forceinline__ void apply_action(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
+                                               uint32_t& elim_seen) {
+    const uint32_t m = rdlane(av.meta, PID);
+    if (!(m & 16u)) return;              // nil action
+    if (!((alive >> PID) & 1u)) return;  // action_processor.go:56-60 (Alive as last written, H2)
+    uint32_t code = m & 15u;
+    int fa = 0, ta = 0, ft = 0, tt = 0;
+    if (!code) {
+      ft = (int)rdlane((uint32_t)av.ft, PID);
+      tt = (int)rdlane((uint32_t)av.tt, PID);
+      fa = army_get(ft);
+      ta = army_get(tt);
+      if (!bit_at_p(own, PID, ft)) code = GVEC_ERR_NOT_OWNED;         // action.go:82-84
+      else if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;           // :87-89
+      else if (bit_at(mtn, tt)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;  // :96-98
+    }
+    if (code) {  // action_processor.go:66-77: remember the FIRST error, keep going
+      first_err = first_err ? first_err : code;
+      return;
+    }
+    int n = (m & 32u) ? (fa / 2) : (fa - 1);  // movement.go:40-49
+    n = (n == 0) ? 1 : n;
+    const uint32_t fbit = tile_bit(ft), tbit = tile_bit(tt);
+    army_set(ft, fa - n);  // :54
+    chg |= fbit | tbit;    // :57-60
+    if (bit_at_p(own, PID, tt)) {  // :62-66 own tile: consolidate
+      army_set(tt, ta + n);
+    } else if (n > ta) {  // :69-82 capture (ties favour the defender)
+      int prev = -1;
+#pragma unroll
+      for (int q = 0; q < MAXP; ++q)
+        if (bit_at_p(own, q, tt)) prev = q;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        own[k] &= ~tbit;  // the bit sits in every row: cleared for every player
+        if (k == PID / PPR) own[k] |= in_row_of(PID) ? tbit : 0u;
+      }
+      army_set(tt, n - ta);
+      vch |= tbit;  // action_processor.go:84-86
+      // movement.go:105-108
+      if (bit_at(gen, tt) && prev >= 0 && !((elim_seen >> prev) & 1u)) {
+        orders |= (uint64_t)((uint32_t)prev | ((uint32_t)PID << 4)) << (8 * n_orders);
+        n_orders++;
+        elim_seen |= 1u << prev;
+      }
+    } else {
+      army_set(tt, ta - n);  // :85
+    }
+  }
+  template <int PID>
+  __device__ __forceinline__ void act_chain(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
+                                            uint32_t& elim_seen) {
+    if constexpr (PID < MAXP) {
+      if (PID < P) apply_action<PID>(av, first_err, orders, n_orders, elim_seen);
+      act_chain<PID + 1>(av, first_err, orders, n_orders, elim_seen);
+    }
+  }
+
+  // ---- Engine.handleEliminationsAndTileTurnover (engine.go:118-152) ----------------------------------
+  __device__ __forceinline__ void eliminate(uint64_t orders, int n_orders) {
+    for (int e = 0; e < n_orders; ++e) {
+      const int v = (int)((orders >> (8 * e)) & 15u), nw = (int)((orders >> (8 * e + 4)) & 15u);
+      uint32_t tiles = 0u;  // victim's listed tiles still owned by the victim (:130-131, H4): its row only
+#pragma unroll
+      for (int k = 0; k < NR; ++k) tiles |= (lane_player(k) == v) ? (lst[k] & own[k]) : 0u;
+      tiles = or_rows(tiles);  // now in every row
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        own[k] = (lane_player(k) == v) ? (own[k] & ~tiles) : own[k];
+        own[k] = (lane_player(k) == nw) ? (own[k] | tiles) : own[k];
+      }
+      hdr_set(H_GIDX + v, 0xFFFFFFFFu);  // :141 GeneralIdx = -1
+      chg |= tiles;                      // :133-134
+      vch |= tiles;
+      alive &= ~(1u << v);  // :140
+    }
+  }
+
+  // ---- TurnProcessor.ProcessTurn (turn_processor.go:29-77) ------------------------------------------
+  __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, bool& aborted) {
+    aborted = false;
+    turn++;  // initializeTurn :124-135
+    update_fog();
+    chg = 0u;
+    vch = 0u;
+    uint32_t first_err = 0u, elim_seen = 0u;
+    uint64_t orders = 0ull;
+    int n_orders = 0;
+    const ActVec av = prevalidate(acts_lo, acts_hi);
+    const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
+    if (present) {
+      army_to_lds();
+      act_chain<0>(av, first_err, orders, n_orders, elim_seen);
+      army_from_lds();
+    }
+    if (n_orders > 0) {  // engine.go:101-109
+      eliminate(orders, n_orders);
+      update_stats();
+    }
+    if (first_err) {  // engine.go:111-113 -> turn_processor.go:55-57 (H5)
+      aborted = true;
+      return first_err;
+    }
+    production(A.prod_general, A.prod_city, A.prod_normal, A.interval);  // :60
+    update_stats();                                                       // :65,170-179
+    check_game_over();
+    return 0u;
+  }
+
+  // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73); see Board::legal_masks ----
+  template <bool SERIALIZER = false>
+  __device__ __forceinline__ void legal_targets(uint32_t (&okp)[MPASS], int fd) const {
+    const uint32_t notm = ~mtn & valid;
+    const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);
+    const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;
+    const uint32_t ok1 = SERIALIZER ? ok_dn : ok_rt, ok2 = SERIALIZER ? ok_lf : ok_dn, ok3 = SERIALIZER ? ok_rt : ok_lf;
+#pragma unroll
+    for (int k = 0; k < MPASS; ++k) {
+      const int j = lane_id() + 64 * k;
+      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
+      const int addr = (j - d * fd) << 2;  // row 0, column j mod fd
+      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
+      const uint32_t g = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
+      okp[k] = (j < 4 * fd) ? g : 0u;
+    }
+  }
+  template <bool SERIALIZER = false>
+  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd, const uint32_t (&okp)[MPASS]) const {
+    uint32_t gt1 = 0u;  // army > 1, in every row
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
+    uint32_t src[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1 - all players of the register at once
+      const uint32_t m = SERIALIZER ? (own[k] & gt1) : (lst[k] & own[k] & gt1);
+      src[k] = (SERIALIZER || lane_flag(alive, k)) ? m : 0u;
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < MPASS; ++k2) {
+      const int j = lane_id() + 64 * k2;
+      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
+      const int c = j - d * fd;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) out[p][k2] = bperm((((p % PPR) * ROWL) + c) << 2, src[p / PPR]) & okp[k2];  // cross-lane: unconditional
+    }
+  }
+  template <bool SERIALIZER = false>
+  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
+    uint32_t okp[MPASS];
+    legal_targets<SERIALIZER>(okp, fd);
+    legal_masks<SERIALIZER>(out, fd, okp);
+  }
+};
+
+}  // namespace gvec

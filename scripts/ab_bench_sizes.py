@@ -1,0 +1,19 @@
+import sys, os, statistics as st
+sys.path.insert(0, "/root/repo")
+import torch
+from generalsreinforcementlearning_amd import _lib
+from generalsreinforcementlearning_amd.vec_engine import VecEngine
+cfgs = [(32768, 32, 32, 8), (65536, 25, 25, 4), (65536, 15, 15, 2)]
+for (B, W, H, P) in cfgs:
+    for path in sys.argv[1:]:
+        L = _lib.load_from(os.path.abspath(path))
+        e = VecEngine(B, W, H, P, auto_reset=True, lib=L, stream=torch.cuda.current_stream().cuda_stream)
+        e.reset_generated(5); e.build_board_pool(1024, 7); e.rollout(10, 1, 0, fused=False, want_stats=False)
+        ts = []
+        for r in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); e.rollout(50, 1, 0, fused=False, want_stats=False); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / 50)
+        m = st.median(ts)
+        print(f"{B}x{W}x{H} P{P} {os.path.basename(path)}: {m*1e3:.1f} us/step -> {B/m/1e3:.1f} M steps/s", flush=True)
+        del e

@@ -27,6 +27,9 @@ CONFIGS = [
     ("tiny_boards", 64, [(3, 3, 2), (5, 5, 2), (8, 8, 3), (7, 5, 2), (2, 9, 2)], True),
     ("wide_p8", 48, [(25, 25, 8), (32, 32, 5), (32, 17, 6), (19, 31, 7)], True),
     ("odd_strides", 64, [(14, 16, 4), (21, 21, 3), (12, 8, 4)], True),
+    ("25x25_p4", 48, [(25, 25, 4), (22, 24, 3)], True),
+    ("20x20_p8", 48, [(20, 20, 8), (16, 21, 6), (21, 21, 5)], True),
+    ("25x25_p8", 32, [(25, 25, 8), (24, 26, 7)], True),
 ]
 
 

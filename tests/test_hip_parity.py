@@ -207,6 +207,11 @@ CONFIGS = [
     ("mixed_padded", 192, [(10, 10, 2), (15, 15, 3), (20, 20, 4)], True, 250, 10),
     ("tiny_boards", 64, [(3, 3, 2), (5, 5, 2), (8, 8, 3), (7, 5, 2)], True, 120, 20),
     ("wide_25x25_p8", 32, [(25, 25, 8), (32, 32, 5), (32, 17, 6)], True, 150, 5),
+    # the remaining register layouts of the step kernel (gvec_packed.hpp): <4,10> two players per 32-lane
+    # row pair, <8,7> two registers of four 16-lane rows, <8,10> four registers of two rows
+    ("25x25_p4", 48, [(25, 25, 4), (22, 24, 3)], True, 150, 5),
+    ("20x20_p8", 48, [(20, 20, 8), (16, 21, 6), (21, 21, 5)], True, 150, 5),
+    ("25x25_p8", 32, [(25, 25, 8), (24, 26, 7)], True, 120, 5),
 ]
 
 
