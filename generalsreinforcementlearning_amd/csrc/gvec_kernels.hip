@@ -239,6 +239,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
 // scales with the board state the variant must hold: planes + army slots + mask words + ~40
 // working registers.
 constexpr int rollout_waves(int maxp, int nslot) {
+  // (the 8-player variants run on PBoard and need fewer plane registers, but asking for more waves there
+  // only brings the spills back: measured 32x32 8P, 101 us/turn with this bound, 160 us with a tighter one)
   const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + 40;
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
@@ -250,7 +252,9 @@ constexpr int rollout_waves(int maxp, int nslot) {
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
-  using B = Board<MAXP, NSLOT>;  // measured: the fused loop is 3 % faster on the unpacked registers (same VALU count, shorter chains)
+  // measured (one-process A/B of the fused loop): 20x20 4P 3 % faster on the unpacked registers (same VALU
+  // count, shorter chains), 25x25 4P a tie, 32x32 8P 11 % faster packed (29 plane registers become 11)
+  using B = std::conditional_t<packed_variant(MAXP) && MAXP >= 8, PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
