@@ -241,7 +241,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
 constexpr int rollout_waves(int maxp, int nslot) {
   // (the 8-player variants run on PBoard and need fewer plane registers, but asking for more waves there
   // only brings the spills back: measured 32x32 8P, 101 us/turn with this bound, 160 us with a tighter one)
-  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + 40;
+  // Boards above 448 tiles carry two mask words per player and longer slot loops: a spill inside the turn
+  // loop costs far more than a wave (measured <4,10>, 25x25 4P: 91 us/turn at 5 waves, 135 at 6, 150 at 7).
+  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + (nslot >= 10 ? 60 : 40);
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
   return w > 8 ? 8 : (w < 2 ? 2 : w);
@@ -253,8 +255,9 @@ template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
   // measured (one-process A/B of the fused loop): 20x20 4P 3 % faster on the unpacked registers (same VALU
-  // count, shorter chains), 25x25 4P a tie, 32x32 8P 11 % faster packed (29 plane registers become 11)
-  using B = std::conditional_t<packed_variant(MAXP) && MAXP >= 8, PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
+  // count, shorter chains), 32x32 8P 11 % faster packed (29 plane registers become 11); boards above 448 tiles
+  // run packed as well (fewer registers to spill)
+  using B = std::conditional_t<packed_variant(MAXP) && (MAXP >= 8 || NSLOT >= 10), PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
   constexpr int MPASS = B::MPASS;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
