@@ -304,6 +304,30 @@ def test_rollout_matches_oracle_rollout(g, fused):
     assert np.array_equal(eng.legal_action_mask_bits(), ora.legal_mask())
 
 
+@pytest.mark.parametrize("sizes", [[(25, 25, 4), (22, 24, 3)], [(32, 32, 8), (25, 25, 8), (32, 17, 6)], [(20, 20, 8), (21, 21, 5)],
+                                   [(25, 25, 2), (32, 32, 2)]],
+                         ids=["25x25_p4", "32x32_p8", "20x20_p8", "large_p2"])
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_turn_launch"])
+def test_rollout_matches_oracle_on_every_register_layout(g, fused, sizes):
+    """The fused and per-turn rollouts of the larger kernel variants (packed layouts of gvec_packed.hpp,
+    two mask words per player) against the oracle's rollout, auto-reset included."""
+    B, K = 96, 120
+    per_env = [sizes[i % len(sizes)] for i in range(B)]
+    mw, mh, mp = max(s[0] for s in per_env), max(s[1] for s in per_env), max(s[2] for s in per_env)
+    army, owner, typ, w, h, p = H.gen_boards(77, per_env, mw, mh)
+    eng = g.VecEngine(B, mw, mh, mp, auto_reset=True)
+    ora = O.OracleBatch(B, mw, mh, mp)
+    eng.reset(army, owner, typ, w, h, p)
+    ora.reset(army, owner, typ, w, h, p)
+    eng.build_board_pool(13, 99)
+    ora.set_pool(13, 99)
+    stats = eng.rollout(K, seed=4242, invalid_permille=10, fused=fused)
+    steps = ora.rollout(K, 4242, 10)
+    H.assert_states_equal(eng.game_state(), ora.read_state(), f"rollout fused={fused}")
+    assert stats["env_steps"] == steps
+    assert np.array_equal(eng.legal_action_mask_bits(), ora.legal_mask())
+
+
 def test_auto_reset_matches_oracle(g):
     # tiny boards so games actually finish; every finished env is re-dealt from the pool
     B, K, pool = 256, 400, 37
