@@ -16,7 +16,7 @@
  *     delivered in int32 err[B] using the sentinel numbering of
  *     internal/game/core/errors.go:8-17 == proto/common/v1/common.proto:39-48.
  *   - Buffers are caller-owned, env-major.  `mem` says where they live:
- *     GVEC_MEM_HOST (library stages through its own pinned buffers) or
+ *     GVEC_MEM_HOST (the library copies through its own device staging buffers) or
  *     GVEC_MEM_DEVICE (pointers are HIP device pointers on the handle's device;
  *     no host copy, work is enqueued on the handle's stream and NOT synchronised).
  *   - Tile planes use the reference's row-major index  t = y*W + x
