@@ -45,11 +45,17 @@ def proto_view(owner, army, type_, visible, fog):
     return {"type": t, "owner": o, "army": a, "visible": visible}
 
 
-def build_observation(view, player_id, turn_count, max_turns, width, height):
-    """GeneralsEnv._get_observation (generals_env.py:291-342).  view arrays [B, N] -> [B, 9, H, W]."""
+def build_observation(view, player_id, turn_count, max_turns, width, height, out=None):
+    """GeneralsEnv._get_observation (generals_env.py:291-342).  view arrays [B, N] -> [B, 9, H, W].
+    `out`: a float32 buffer of that shape to fill (a fresh 9*N*B-float array costs more in page faults
+    than every channel below put together)."""
     B = view["owner"].shape[0]
     n = width * height
-    obs = np.zeros((B, 9, n), np.float32)
+    if out is None:
+        obs = np.zeros((B, 9, n), np.float32)
+    else:
+        obs = out.reshape(B, 9, n)
+        obs[:, 8] = 0.0
     own, army, typ = view["owner"][:, :n], view["army"][:, :n], view["type"][:, :n]
     obs[:, 0] = view["visible"][:, :n]                                               # :312-314
     obs[:, 1] = np.where(own == player_id, 0.5, np.where(own >= 0, 1.0, 0.0))        # :316-322
@@ -145,6 +151,8 @@ class GeneralsVecEnv:
         self._needs_reset = np.zeros(num_envs, bool)
         self._stats = None
         self.valid_actions_mask = None
+        self._obs_bufs = [np.zeros((num_envs, 9, board_height, board_width), np.float32) for _ in range(2)]
+        self._obs_flip = 0
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _read(self):
@@ -155,7 +163,10 @@ class GeneralsVecEnv:
         return view, stats
 
     def _observe(self, view):
-        obs = build_observation(view, self.player_id, self.turn_count, self.max_turns, self.board_width, self.board_height)
+        # two observation buffers alternate: the array returned by step k stays intact until step k + 2
+        self._obs_flip ^= 1
+        obs = build_observation(view, self.player_id, self.turn_count, self.max_turns, self.board_width, self.board_height,
+                                out=self._obs_bufs[self._obs_flip])
         self.valid_actions_mask = valid_actions_mask(view, self.player_id, self.board_width, self.board_height)
         return obs
 
