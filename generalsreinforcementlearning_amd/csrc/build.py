@@ -16,7 +16,7 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libgvec_hip.so")
 SRCS = ["gvec_kernels.hip", "gvec_api.hip"]
-DEPS = ["gvec_device.hpp", "gvec_launch.hpp", os.path.join(ROOT, "include", "generals_vec.h")]
+DEPS = ["gvec_device.hpp", "gvec_packed.hpp", "gvec_launch.hpp", os.path.join(ROOT, "include", "generals_vec.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
