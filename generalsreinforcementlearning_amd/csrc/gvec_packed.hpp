@@ -212,10 +212,14 @@ struct PBoard {
     const int lane = lane_id();
     return __builtin_amdgcn_sbfe((int32_t)bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
-  __device__ __forceinline__ void scatter(uint32_t& plane, unsigned long long ballot, int s) const {  // into every row
-    plane = (col() == 2 * s) ? (uint32_t)ballot : plane;
-    plane = (col() == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
+  // tile predicates -> flat plane: row 0 first (lane == constant: the selects take scalar masks, no vector
+  // compares), then one ds_bpermute copies row 0 into every row
+  __device__ __forceinline__ void scatter_row0(uint32_t& plane, unsigned long long ballot, int s) const {
+    const int lane = lane_id();
+    plane = (lane == 2 * s) ? (uint32_t)ballot : plane;
+    plane = (lane == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
   }
+  static __device__ __forceinline__ uint32_t replicate_row0(uint32_t plane) { return bperm(col() << 2, plane); }
   // popcount of a replicated plane (row 0 only)
   __device__ __forceinline__ int count_shared(uint32_t plane) const {
     return (int)wave_sum((lane_id() < ROWL) ? (uint32_t)__builtin_popcount(plane) : 0u);
@@ -517,7 +521,8 @@ struct PBoard {
   __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd, const uint32_t (&okp)[MPASS]) const {
     uint32_t gt1 = 0u;  // army > 1, in every row
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
+    for (int s = 0; s < NSLOT; ++s) scatter_row0(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
+    gt1 = replicate_row0(gt1);
     uint32_t src[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
