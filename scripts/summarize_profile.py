@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarises gpurun_out/prof_<tag>/ (made by scripts/profile_gpu.sh) into profiles/<tag>_summary.json/.md
 and copies the rocprofv3 kernel_stats.csv next to it."""
+import os
 import collections, csv, glob, json, os, shutil, statistics as st, sys
 
 tag = sys.argv[1]
@@ -8,7 +9,7 @@ kernel = sys.argv[2] if len(sys.argv) > 2 else "step_kernel"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 out = {"tag": tag, "kernel_filter": kernel}
-ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+ks = sorted(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)  # newest run of the tag
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(ks[0])):
@@ -21,7 +22,8 @@ if ks:
             out["percent_of_gpu_time"] = float(r["Percentage"])
 counters = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
-    fs = glob.glob(f"{src}/{p}/*/*_counter_collection.csv")
+    # a tag that was profiled twice keeps both runs' files after gpurun merges them back: use the newest
+    fs = sorted(glob.glob(f"{src}/{p}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if not fs:
         continue
     d = collections.defaultdict(list)
