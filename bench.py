@@ -15,10 +15,17 @@ from a pre-generated board pool (auto-reset).
 Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM bandwidth with
 SURVEY 8(d)'s algorithmic bytes per env-step; `cpu_baseline` times the CPU oracle (a C
 restatement of the Go engine: kind "port") on the host cores on a bounded sample.
+
+Scaling modes (N > 1): the default is weak scaling (--envs-per-gpu boards on every rank);
+`--total-envs T` is strong scaling - BASELINE.json configs[3] as stated, 262,144 boards sharded
+across the ranks with sharding.shard_range - and `config.workload` says which one ran.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -39,6 +46,47 @@ def step_kernel_name(w, h, p):
     nslot = next(n for n in (1, 2, 4, 7, 10, 16) if n * 64 >= w * h)
     odd = w * h <= 32 * (2 * nslot - 1)
     return f"gvec::step_kernel<{maxp}, {nslot}, true, {'true' if odd else 'false'}>"
+
+
+def kernel_source_hash():
+    """Identifies the kernel build a PMC traffic figure belongs to (profiles/pmc_traffic.json is stamped with it)."""
+    d = os.path.join(ROOT, "generalsreinforcementlearning_amd", "csrc")
+    hh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            hh.update(open(os.path.join(d, f), "rb").read())
+    return hh.hexdigest()[:16]
+
+
+def go_probe():
+    """The Go engine itself can only be timed where a Go toolchain AND the reference module exist
+    (bench/go/step_bench_test.go; GRL_REFERENCE_DIR = a checkout of the reference).  Probed, never assumed."""
+    go = shutil.which("go")
+    if go is None:
+        return {"go": None, "status": "Go unavailable on this host (shutil.which('go') is None)"}
+    try:
+        ver = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:  # a broken toolchain is an absent one
+        return {"go": go, "status": f"Go unavailable on this host (`go version` failed: {e})"}
+    ref = os.environ.get("GRL_REFERENCE_DIR")
+    if not ref or not os.path.exists(os.path.join(ref, "go.mod")):
+        return {"go": go, "version": ver, "status": "Go present; set GRL_REFERENCE_DIR to a checkout of the reference to time Engine.Step "
+                                                    "with bench/go/step_bench_test.go (the reference does not travel with this repository)"}
+    try:
+        dst = os.path.join(ref, "internal", "game", "zz_gvec_step_bench_test.go")
+        shutil.copy(os.path.join(ROOT, "bench", "go", "step_bench_test.go"), dst)
+        try:
+            r = subprocess.run([go, "test", "./internal/game/", "-run", "^$", "-bench", "BenchmarkEngineStep20x20P4", "-benchtime", "5s"],
+                               cwd=ref, capture_output=True, text=True, timeout=300)
+        finally:
+            os.unlink(dst)
+        line = next((l for l in r.stdout.splitlines() if l.startswith("BenchmarkEngineStep20x20P4")), None)
+        if line is None:
+            return {"go": go, "version": ver, "status": "go test produced no benchmark line", "stderr": r.stderr[-400:]}
+        ns = float(line.split()[2])
+        return {"go": go, "version": ver, "status": "ok", "engine_step_ns_per_op": ns, "env_steps_per_s_one_goroutine": 1e9 / ns, "line": line}
+    except Exception as e:
+        return {"go": go, "version": ver, "status": f"go benchmark failed: {e}"}
 
 
 def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
@@ -73,7 +121,17 @@ def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
             "single_thread_value": s1 / d1,
             "sample": f"{envs} boards {w}x{h} P{p} fog={'on' if fog else 'off'} x {turns} turns, oracle random agent + "
                       f"Engine.Step restatement (no mask packing), OpenMP over boards; {dt:.1f} s of CPU work",
-            "note": "C restatement of the Go engine (oracle/generals_oracle.c); the Go toolchain is absent on this host"}
+            "note": "C restatement of the Go engine (oracle/generals_oracle.c), never the Go engine itself",
+            "go_reference": go_probe()}
+
+
+def shard_plan(args, world, rank):
+    """-> (boards of this rank, boards of the whole job, "weak" | "strong")."""
+    if args.total_envs > 0:
+        from generalsreinforcementlearning_amd.sharding import shard_range
+        _, n = shard_range(args.total_envs, world, rank)
+        return n, args.total_envs, "strong"
+    return args.envs_per_gpu, args.envs_per_gpu * world, "weak"
 
 
 class _NullEngine:
@@ -104,7 +162,7 @@ def rehearse_cpu(args):
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
-    B = args.envs_per_gpu
+    B, total, mode = shard_plan(args, world, rank)
     eng = _NullEngine(64)
     ge = min(args.gather_envs, B)
     rg = RecordGather(ge * eng.state_bytes_per_env(), torch.device("cpu"), dst=0) if ge > 0 else None
@@ -126,7 +184,8 @@ def rehearse_cpu(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathers": got,
-                          "value": world * B * args.steps / float(t.item()), "scaling": "weak"}), flush=True)
+                          "value": total * args.steps / float(t.item()), "scaling": mode, "total_envs": total,
+                          "envs_rank0": B}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,7 +195,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=262144)
+    ap.add_argument("--envs-per-gpu", type=int, default=262144, help="weak scaling: boards on every rank")
+    ap.add_argument("--total-envs", type=int, default=0,
+                    help="strong scaling: this many boards in total, sharded across the ranks (BASELINE configs[3]: 262144)")
+    ap.add_argument("--prewarm-s", type=float, default=0.75,
+                    help="untimed clock-settle phase before the counted warmup: step launches for at least this many seconds")
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--height", type=int, default=20)
     ap.add_argument("--players", type=int, default=4)
@@ -173,7 +236,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream()
 
-    B, W, H, P = args.envs_per_gpu, args.width, args.height, args.players
+    W, H, P = args.width, args.height, args.players
+    B, total_envs, scaling = shard_plan(args, world, rank)
     eng = g.VecEngine(B, W, H, P, fog_of_war=bool(args.fog), device=local_rank, auto_reset=True, stream=stream.cuda_stream)
     eng.reset_generated(args.seed * 1000003 + rank)
     eng.build_board_pool(args.pool, args.seed * 7919 + rank)
@@ -209,6 +273,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # clock-settle phase (untimed, not counted as warmup): a cold MI355X needs a few hundred ms of load before its
+    # clocks and HBM settle - a 20-step run measured straight after the reset reads ~9 % slower than a 200-step one
+    prewarm_steps, tp = 0, time.perf_counter()
+    while time.perf_counter() - tp < args.prewarm_s:
+        for _ in range(16):
+            eng.rollout(1, seed + 7, 0, fused=False, want_stats=False)
+        prewarm_steps += 16
+        torch.cuda.synchronize()
+    prewarm_s = time.perf_counter() - tp
     for k in range(args.warmup):
         one_step(k)
     sync_all()
@@ -243,29 +316,39 @@ def main():
         n = world
         abytes = algorithmic_bytes(W, H, P, True)
         achieved = abytes * B / (kernel_ms / 1e3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel build (profiles/pmc_traffic.json carries the
+        # hash of the kernel sources it was measured on; a figure from another build is dropped, not reported)
+        traffic, traffic_note = None, "no PMC record for this kernel build"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("envs") == B and rec.get("board") == [W, H, P]:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                if rec.get("envs") == B and rec.get("board") == [W, H, P] and rec.get("kernel_source_hash") == kernel_source_hash():
+                    traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None
+        mode_txt = (f"{total_envs} boards sharded over {n} GPU(s) ({B} on rank 0; strong scaling)" if scaling == "strong"
+                    else f"{B} boards/GPU (weak scaling)")
         out = {
-            "metric": "env steps/sec (whole node), 20x20 4P fog-on, bit-exact vs Go ref",
-            "value": n * B * args.steps / elapsed,
+            "metric": "env steps/sec (whole node), 20x20 4P fog-on; state bit-exact vs the C restatement of the Go engine "
+                      "(the reference's own test vectors pass on both)",
+            "value": total_envs * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{B} boards/GPU x {W}x{H} {P}P fog-{'on' if args.fog else 'off'} + legal mask, on-device random "
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic", "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
+            "config": {"workload": f"{mode_txt} x {W}x{H} {P}P fog-{'on' if args.fog else 'off'} + legal mask, on-device random "
                                    f"agent, auto-reset pool {args.pool}, 1 turn per launch",
-                       "envs_per_gpu": B, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
+                       "envs_per_gpu": B, "total_envs": total_envs, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
                        "gather_envs_per_step": (args.gather_envs if n > 1 else 0)},
+            # achieved / frac: ALGORITHMIC bytes over the kernel's measured time - the contract's figure.
+            # traffic_*: the bytes the kernel really moves (PMC), when a record for this build exists.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_gbs": (traffic / (kernel_ms / 1e3) / 1e9 if traffic else None),
+                         "traffic_frac": (traffic / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS if traffic else None),
+                         "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
                          "units_per_launch": B, "kernel_ms": kernel_ms},
         }
         if fused:

@@ -38,7 +38,8 @@ struct gvec_handle {
   hipStream_t stream;
   uint32_t* d_hdr = nullptr;
   uint32_t* d_rows = nullptr;
-  int32_t* d_army = nullptr;
+  uint32_t* d_army16 = nullptr;  // narrow armies (u16 pairs), army_dw / 2 dwords per env
+  int32_t* d_army32 = nullptr;   // wide escape (int32), army_dw dwords per env: only envs flagged HF_WIDE use it
   uint32_t* d_legal = nullptr;
   gvec_action* d_actions = nullptr;
   int32_t* d_err = nullptr;
@@ -49,20 +50,45 @@ struct gvec_handle {
   int snap_dw = 0;
   uint32_t* p_hdr = nullptr;
   uint32_t* p_rows = nullptr;
-  int32_t* p_army = nullptr;
+  uint32_t* p_army16 = nullptr;
+  int32_t* p_army32 = nullptr;
   int pool_size = 0;
   uint64_t pool_seed = 0;
   bool legal_valid = false;
+  // grow-only device staging for GVEC_MEM_HOST calls: slot i serves the i-th staged argument of a call.
+  // Owned by the handle, reused by every call (work on one handle is serialised on its stream), freed by
+  // gvec_destroy - the host path allocates nothing in steady state.
+  static constexpr int kStageSlots = 24;
+  void* stage_ptr[kStageSlots] = {};
+  size_t stage_cap[kStageSlots] = {};
 };
 
 namespace {
 
-struct DevBuf {  // scoped device scratch
+// One staged argument of the current call: a view of slot `slot` of the handle's grow-only staging.
+struct DevBuf {
+  gvec_handle* h;
+  int slot;
   void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+  DevBuf(gvec_handle* h_, int slot_) : h(h_), slot(slot_) {}
+  hipError_t alloc(size_t bytes) {
+    if (bytes < 16) bytes = 16;
+    if (h->stage_cap[slot] < bytes) {
+      if (h->stage_ptr[slot]) {
+        hipError_t e = hipStreamSynchronize(h->stream);  // an earlier call's copy may still read it
+        if (e != hipSuccess) return e;
+        (void)hipFree(h->stage_ptr[slot]);
+        h->stage_ptr[slot] = nullptr;
+        h->stage_cap[slot] = 0;
+      }
+      const size_t cap = bytes + bytes / 4;  // a little headroom: fewer re-allocations while a caller grows
+      hipError_t e = hipMalloc(&h->stage_ptr[slot], cap);
+      if (e != hipSuccess) return e;
+      h->stage_cap[slot] = cap;
+    }
+    p = h->stage_ptr[slot];
+    return hipSuccess;
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
   template <typename T>
   T* as() const {
     return reinterpret_cast<T*>(p);
@@ -76,11 +102,13 @@ StepArgs base_args(const gvec_handle* h) {
   memset(&a, 0, sizeof a);
   a.hdr = h->d_hdr;
   a.rows = h->d_rows;
-  a.army = h->d_army;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
   a.legal = h->d_legal;
   a.pool_hdr = h->p_hdr;
   a.pool_rows = h->p_rows;
-  a.pool_army = h->p_army;
+  a.pool_army16 = h->p_army16;
+  a.pool_army32 = h->p_army32;
   a.num_envs = h->cfg.num_envs;
   a.fd = h->fd;
   a.row_dw = h->row_dw;
@@ -163,13 +191,14 @@ int32_t copy_out(gvec_handle* h, const DevBuf& buf, T* dst, size_t count, int32_
     if (r__ != GVEC_OK) return r__; \
   } while (0)
 
-int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* army, const int32_t* env_ids_dev, int dst_begin,
+int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* army16, int32_t* army32, const int32_t* env_ids_dev, int dst_begin,
                       int n, int dst_envs, const gvec_state_view* v /*device pointers*/, bool fresh, bool init) {
   ImportArgs a;
   memset(&a, 0, sizeof a);
   a.hdr = hdr;
   a.rows = rows;
-  a.army = army;
+  a.army16 = army16;
+  a.army32 = army32;
   a.env_ids = env_ids_dev;
   a.dst_begin = dst_begin;
   a.n = n;
@@ -218,14 +247,16 @@ int32_t allocate_handle(gvec_handle* h, const gvec_config* cfg) {
   const size_t B = (size_t)cfg->num_envs;
   HIPCHK(hipMalloc(&h->d_hdr, B * HDR_DW * 4));
   HIPCHK(hipMalloc(&h->d_rows, B * h->row_dw * 4));
-  HIPCHK(hipMalloc(&h->d_army, B * h->army_dw * 4));
+  HIPCHK(hipMalloc(&h->d_army16, B * h->army_dw * 2));
+  HIPCHK(hipMalloc(&h->d_army32, B * h->army_dw * 4));
   HIPCHK(hipMalloc(&h->d_legal, B * h->maxp * h->mask_bytes));
   HIPCHK(hipMalloc(&h->d_actions, B * h->maxp * sizeof(gvec_action)));
   HIPCHK(hipMalloc(&h->d_err, B * 4));
   HIPCHK(hipMalloc(&h->d_status, 16));
   HIPCHK(hipMalloc(&h->d_counters, 6 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(h->d_rows, 0, B * h->row_dw * 4));
-  HIPCHK(hipMemset(h->d_army, 0, B * h->army_dw * 4));
+  HIPCHK(hipMemset(h->d_army16, 0, B * h->army_dw * 2));
+  HIPCHK(hipMemset(h->d_army32, 0, B * h->army_dw * 4));
   HIPCHK(hipMemset(h->d_legal, 0, B * h->maxp * h->mask_bytes));
   HIPCHK(hipMemset(h->d_actions, 0, B * h->maxp * sizeof(gvec_action)));
   HIPCHK(hipMemset(h->d_err, 0, B * 4));
@@ -277,7 +308,8 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   }
   if (cfg->num_envs < 1 || cfg->max_width < 1 || cfg->max_width > GVEC_MAX_DIM || cfg->max_height < 1 ||
       cfg->max_height > GVEC_MAX_DIM || cfg->max_players < 1 || cfg->max_players > GVEC_MAX_PLAYERS ||
-      cfg->normal_growth_interval < 1 || cfg->prod_general < 0 || cfg->prod_city < 0 || cfg->prod_normal < 0) {
+      cfg->normal_growth_interval < 1 || cfg->prod_general < 0 || cfg->prod_city < 0 || cfg->prod_normal < 0 ||
+      cfg->prod_general > 0xFFFFFF || cfg->prod_city > 0xFFFFFF || cfg->prod_normal > 0xFFFFFF) {
     set_err("gvec_create: config out of range");
     return GVEC_E_INVALID;
   }
@@ -315,8 +347,11 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
 int32_t gvec_destroy(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters, h->d_snap, h->p_hdr, h->p_rows, h->p_army};
+  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters,
+                  h->d_snap, h->p_hdr, h->p_rows, h->p_army16, h->p_army32};
   for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (void* p : h->stage_ptr)
     if (p) (void)hipFree(p);
   delete h;
   return GVEC_OK;
@@ -349,7 +384,7 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
     for (int i = 0; i < n; ++i)
       if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return GVEC_E_RANGE;
   HIPCHK(hipSetDevice(h->cfg.device));
-  DevBuf b_ids, b_army, b_owner, b_type, b_w, b_h, b_p;
+  DevBuf b_ids(h, 0), b_army(h, 1), b_owner(h, 2), b_type(h, 3), b_w(h, 4), b_h(h, 5), b_p(h, 6);
   const size_t nt = (size_t)n * h->stride;
   gvec_state_view v;
   memset(&v, 0, sizeof v);
@@ -361,15 +396,15 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
   RET_IF(stage_in(h, b_w, width, (size_t)n, mem, (const int32_t**)&v.width));
   RET_IF(stage_in(h, b_h, height, (size_t)n, mem, (const int32_t**)&v.height));
   RET_IF(stage_in(h, b_p, players, (size_t)n, mem, (const int32_t**)&v.players));
-  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, ids, 0, n, h->cfg.num_envs, &v, true, true));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, ids, 0, n, h->cfg.num_envs, &v, true, true));
   RET_IF(check_status(h, "gvec_reset"));
   return refresh_legal(h);
 }
 
-static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int32_t* army, int count, uint64_t seed,
+static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* army16, int32_t* army32, int count, uint64_t seed,
                              const int32_t* width, const int32_t* height, const int32_t* players) {
   const int chunk = 65536;
-  DevBuf b_army, b_owner, b_type, b_w, b_h, b_p, b_iw, b_ih, b_ip;
+  DevBuf b_army(h, 1), b_owner(h, 2), b_type(h, 3), b_w(h, 4), b_h(h, 5), b_p(h, 6), b_iw(h, 7), b_ih(h, 8), b_ip(h, 9);
   const int cn = count < chunk ? count : chunk;
   HIPCHK(b_army.alloc((size_t)cn * h->stride * 4));
   HIPCHK(b_owner.alloc((size_t)cn * h->stride));
@@ -414,7 +449,7 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, int3
     v.width = m.width;
     v.height = m.height;
     v.players = m.players;
-    RET_IF(import_planes(h, hdr, rows, army, nullptr, first, n, count, &v, true, true));
+    RET_IF(import_planes(h, hdr, rows, army16, army32, nullptr, first, n, count, &v, true, true));
     HIPCHK(hipStreamSynchronize(h->stream));  // staging is reused by the next chunk
   }
   return check_status(h, "map generation");
@@ -424,7 +459,7 @@ int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed, const int32_t* width
                              const int32_t* players) {
   if (!h) return GVEC_E_INVALID;
   HIPCHK(hipSetDevice(h->cfg.device));
-  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army, h->cfg.num_envs, seed, width, height, players));
+  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->cfg.num_envs, seed, width, height, players));
   return refresh_legal(h);
 }
 
@@ -435,15 +470,18 @@ int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed, 
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->p_hdr) (void)hipFree(h->p_hdr);
   if (h->p_rows) (void)hipFree(h->p_rows);
-  if (h->p_army) (void)hipFree(h->p_army);
+  if (h->p_army16) (void)hipFree(h->p_army16);
+  if (h->p_army32) (void)hipFree(h->p_army32);
   h->p_hdr = nullptr;
   h->p_rows = nullptr;
-  h->p_army = nullptr;
+  h->p_army16 = nullptr;
+  h->p_army32 = nullptr;
   h->pool_size = 0;
   HIPCHK(hipMalloc(&h->p_hdr, (size_t)pool_size * HDR_DW * 4));
   HIPCHK(hipMalloc(&h->p_rows, (size_t)pool_size * h->row_dw * 4));
-  HIPCHK(hipMalloc(&h->p_army, (size_t)pool_size * h->army_dw * 4));
-  RET_IF(generate_into(h, h->p_hdr, h->p_rows, h->p_army, pool_size, seed, width, height, players));
+  HIPCHK(hipMalloc(&h->p_army16, (size_t)pool_size * h->army_dw * 2));
+  HIPCHK(hipMalloc(&h->p_army32, (size_t)pool_size * h->army_dw * 4));
+  RET_IF(generate_into(h, h->p_hdr, h->p_rows, h->p_army16, h->p_army32, pool_size, seed, width, height, players));
   h->pool_size = pool_size;
   h->pool_seed = seed;
   return GVEC_OK;
@@ -502,12 +540,14 @@ static int32_t export_range(gvec_handle* h, int32_t env_begin, int32_t n, const 
   const size_t nt = (size_t)n * h->stride, np = (size_t)n * h->maxp, ne = (size_t)n;
   static const gvec_state_view kEmpty = {};
   const gvec_state_view* v = view ? view : &kEmpty;
-  DevBuf b[19];
+  DevBuf b[19] = {{h, 0}, {h, 1}, {h, 2}, {h, 3}, {h, 4}, {h, 5}, {h, 6}, {h, 7}, {h, 8}, {h, 9}, {h, 10}, {h, 11}, {h, 12},
+                  {h, 13}, {h, 14}, {h, 15}, {h, 16}, {h, 17}, {h, 18}};
   ExportArgs a;
   memset(&a, 0, sizeof a);
   a.hdr = h->d_hdr;
   a.rows = h->d_rows;
-  a.army = h->d_army;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
   a.env_begin = env_begin;
   a.n = n;
   a.stride = h->stride;
@@ -578,7 +618,7 @@ int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gve
   }
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t nt = (size_t)n * h->stride, np = (size_t)n * h->maxp, ne = (size_t)n;
-  DevBuf b[12];
+  DevBuf b[12] = {{h, 0}, {h, 1}, {h, 2}, {h, 3}, {h, 4}, {h, 5}, {h, 6}, {h, 7}, {h, 8}, {h, 9}, {h, 10}, {h, 11}};
   gvec_state_view v;
   memset(&v, 0, sizeof v);
   RET_IF(stage_in(h, b[0], view->army, nt, mem, (const int32_t**)&v.army));
@@ -593,7 +633,7 @@ int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gve
   RET_IF(stage_in(h, b[9], view->alive, np, mem, (const uint8_t**)&v.alive));
   RET_IF(stage_in(h, b[10], view->army_count, np, mem, (const int32_t**)&v.army_count));
   RET_IF(stage_in(h, b[11], view->general_idx, np, mem, (const int32_t**)&v.general_idx));
-  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army, nullptr, env_begin, n, h->cfg.num_envs, &v, false, false));
+  RET_IF(import_planes(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, nullptr, env_begin, n, h->cfg.num_envs, &v, false, false));
   RET_IF(check_status(h, "gvec_write_state"));
   return refresh_legal(h);
 }
@@ -667,7 +707,8 @@ static ExperienceArgs exp_args(gvec_handle* h) {
   memset(&a, 0, sizeof a);
   a.hdr = h->d_hdr;
   a.rows = h->d_rows;
-  a.army = h->d_army;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
   a.snap = h->d_snap;
   a.num_envs = h->cfg.num_envs;
   a.fd = h->fd;
@@ -698,7 +739,7 @@ int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, i
   }
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t B = (size_t)h->cfg.num_envs;
-  DevBuf br, bd;
+  DevBuf br(h, 0), bd(h, 1);
   ExperienceArgs a = exp_args(h);
   RET_IF(stage_out(br, rewards, B * h->maxp, mem, &a.rewards));
   RET_IF(stage_out(bd, done, B, mem, &a.done));
@@ -713,7 +754,7 @@ int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
   if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t count = (size_t)h->cfg.num_envs * (player < 0 ? h->maxp : 1) * 9 * h->stride;
-  DevBuf bo;
+  DevBuf bo(h, 0);
   ExperienceArgs a = exp_args(h);
   a.player = player;
   RET_IF(stage_out(bo, out, count, mem, &a.obs));
@@ -727,7 +768,7 @@ int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem) {
   if (!h || !bits) return GVEC_E_INVALID;
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t bytes = (size_t)h->cfg.num_envs * h->maxp * h->mask_bytes;
-  DevBuf bb;
+  DevBuf bb(h, 0);
   StepArgs a = base_args(h);
   uint8_t* dst = nullptr;
   RET_IF(stage_out(bb, bits, bytes, mem, &dst));
@@ -738,29 +779,47 @@ int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem) {
   return GVEC_OK;
 }
 
+static RecordArgs record_args(gvec_handle* h, int32_t env_begin, int32_t n, void* slab) {
+  RecordArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
+  char* d = reinterpret_cast<char*>(slab);
+  const size_t hb = (size_t)n * HDR_DW * 4, rb = (size_t)n * h->row_dw * 4;
+  a.rec_hdr = reinterpret_cast<uint32_t*>(d);
+  a.rec_rows = reinterpret_cast<uint32_t*>(d + hb);
+  a.rec_army = reinterpret_cast<int32_t*>(d + hb + rb);
+  a.env_begin = env_begin;
+  a.n = n;
+  a.fd = h->fd;
+  a.row_dw = h->row_dw;
+  a.max_w = h->cfg.max_width;
+  a.max_h = h->cfg.max_height;
+  a.max_p = h->maxp;
+  a.status = h->d_status;
+  return a;
+}
+
 int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n, void* dst_device) {
   if (!h || !dst_device) return GVEC_E_INVALID;
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0) return GVEC_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
-  char* d = reinterpret_cast<char*>(dst_device);
-  const size_t hb = (size_t)n * HDR_DW * 4, rb = (size_t)n * h->row_dw * 4, ab = (size_t)n * h->army_dw * 4;
-  HIPCHK(hipMemcpyAsync(d, h->d_hdr + (size_t)env_begin * HDR_DW, hb, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(d + hb, h->d_rows + (size_t)env_begin * h->row_dw, rb, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(d + hb + rb, h->d_army + (size_t)env_begin * h->army_dw, ab, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(launch_records(h->var, record_args(h, env_begin, n, dst_device), false, h->stream));
   return GVEC_OK;
 }
 
 int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n, const void* src_device) {
   if (!h || !src_device) return GVEC_E_INVALID;
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0) return GVEC_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
-  const char* d = reinterpret_cast<const char*>(src_device);
-  const size_t hb = (size_t)n * HDR_DW * 4, rb = (size_t)n * h->row_dw * 4, ab = (size_t)n * h->army_dw * 4;
-  HIPCHK(hipMemcpyAsync(h->d_hdr + (size_t)env_begin * HDR_DW, d, hb, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_rows + (size_t)env_begin * h->row_dw, d + hb, rb, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_army + (size_t)env_begin * h->army_dw, d + hb + rb, ab, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(launch_records(h->var, record_args(h, env_begin, n, const_cast<void*>(src_device)), true, h->stream));
   h->legal_valid = false;
-  return GVEC_OK;
+  // every record's header was checked on the device before anything was taken from it
+  return check_status(h, "gvec_import_records");
 }
 
 void* gvec_device_buffer(gvec_handle* h, int32_t which) {
@@ -768,7 +827,8 @@ void* gvec_device_buffer(gvec_handle* h, int32_t which) {
   switch (which) {
     case 0: return h->d_hdr;
     case 1: return h->d_rows;
-    case 2: return h->d_army;
+    case 2: return h->d_army16;
+    case 6: return h->d_army32;
     case 3: return h->d_legal;
     case 4: return h->d_actions;
     case 5: return h->d_err;

@@ -30,14 +30,20 @@
 
 #include "../../include/generals_vec.h"
 
+// clang has no __builtin for v_writelane_b32: bind the LLVM intrinsic directly (value and lane select must be
+// wave-uniform; the backend moves a run-time lane select to M0)
+extern "C" __device__ int gvec_llvm_writelane(int value, int lane, int vdst_in) __asm("llvm.amdgcn.writelane.i32");
+
 namespace gvec {
 
 // ---- resident record layout (per env) -------------------------------------------------
-// hdr  : HDR_DW u32      planes : M*FD u32 (+pad to 4), plane-major [m][i]     army : NSLOT*64 i32
+// hdr  : HDR_DW u32      planes : M*FD u32 (+pad to 4), plane-major [m][i]
+// army : NARROW block, NSLOT*64 u16 (the default), or - header flag HF_WIDE - the env's block of the
+//        int32 escape array, NSLOT*64 i32 (see "army storage" below)
 constexpr int HDR_DW = 24;
 enum : int {
   H_TURN = 0,     // GameState.Turn
-  H_DIMS = 1,     // W | H<<8 | P<<16 | flags<<24   (flags: bit0 Engine.gameOver, bit1 FogOfWarEnabled)
+  H_DIMS = 1,     // W | H<<8 | P<<16 | flags<<24   (flags: bit0 Engine.gameOver, bit1 FogOfWarEnabled, bit2 wide armies)
   H_STATUS = 2,   // alive bits | last err<<16
   H_EPISODE = 3,  // re-deal counter (auto-reset)
   H_ARMYCNT = 4,  // [8] Player.ArmyCount
@@ -47,7 +53,7 @@ enum : int {
   H_CNT_ABORT = 22,
   H_CNT_DONE = 23
 };
-constexpr uint32_t HF_DONE = 1u, HF_FOG = 2u;
+constexpr uint32_t HF_DONE = 1u, HF_FOG = 2u, HF_WIDE = 4u;
 
 // plane order inside the planes block; the last three never change after reset
 template <int MAXP>
@@ -63,15 +69,17 @@ constexpr uint32_t KF_LMVALID = 16u;   // args.legal already holds the masks of 
 
 struct StepArgs {
   uint32_t* hdr;
-  uint32_t* rows;  // the planes block
-  int32_t* army;
+  uint32_t* rows;    // the planes block
+  uint32_t* army16;  // narrow armies, NSLOT*32 dwords per env
+  int32_t* army32;   // wide escape, NSLOT*64 dwords per env
   const gvec_action* actions;  // [B][pstride] (ignored with KF_AGENT)
   gvec_action* actions_out;    // optional: where the agent records what it played
   int32_t* err;                // [B] or null
   uint32_t* legal;             // [B][pstride][mask_dw]
   const uint32_t* pool_hdr;
   const uint32_t* pool_rows;
-  const int32_t* pool_army;
+  const uint32_t* pool_army16;
+  const int32_t* pool_army32;
   int32_t num_envs, fd, row_dw, mask_dw, pool_size;  // fd = dwords per plane = ceil(max tiles / 32)
   int32_t pstride;  // players per env in actions / legal buffers (gvec_config.max_players)
   int32_t prod_general, prod_city, prod_normal, interval;
@@ -79,6 +87,74 @@ struct StepArgs {
   uint32_t agent_noop, agent_half;  // gvec_set_agent_mix thresholds (of 65536)
   uint32_t flags, seed_lo, seed_hi, pool_seed_lo, pool_seed_hi;
 };
+
+// ---- army storage ------------------------------------------------------------------------
+// Tile.Army is a Go int (core/board.go:9).  On the device it is computed in int32 registers and
+// stored in one of two forms, chosen per env at every store:
+//   NARROW  u16, when every army of the board is in [0, 65535] (virtually always): two 64-tile slots
+//           share a dword - dword 64k+l = army(slot 2k, lane l) | army(slot 2k+1, lane l) << 16 - so one
+//           256-byte wave access moves 128 tiles; an odd last slot is 64 halfwords (one 128-byte line).
+//           NSLOT*128 bytes per env: 896 B instead of 1,792 B at 20x20.
+//   WIDE    int32 in the env's block of the escape array (header flag HF_WIDE), as soon as one army
+//           leaves that range.  Exact for everything an int32 can hold; the env returns to NARROW at
+//           the first store where it fits again.
+// Nothing is ever clamped: the pair (flag, block) always holds the exact int32 value.
+struct ArmyRef {
+  uint32_t* n;  // this env's narrow block (NSLOT*32 dwords)
+  int32_t* w;   // this env's wide block   (NSLOT*64 dwords)
+};
+struct ArmyCRef {
+  const uint32_t* n;
+  const int32_t* w;
+  __device__ __forceinline__ ArmyCRef(const uint32_t* n_, const int32_t* w_) : n(n_), w(w_) {}
+  __device__ __forceinline__ ArmyCRef(const ArmyRef& r) : n(r.n), w(r.w) {}
+};
+template <int NSLOT>
+__device__ __forceinline__ ArmyRef army_ref(uint32_t* a16, int32_t* a32, int env) {
+  return ArmyRef{a16 + (size_t)env * (NSLOT * 32), a32 + (size_t)env * (NSLOT * 64)};
+}
+template <int NSLOT>
+__device__ __forceinline__ ArmyCRef army_cref(const uint32_t* a16, const int32_t* a32, int env) {
+  return ArmyCRef(a16 + (size_t)env * (NSLOT * 32), a32 + (size_t)env * (NSLOT * 64));
+}
+template <int NSLOT>
+__device__ __forceinline__ void army_load_narrow(int32_t (&army)[NSLOT], const uint32_t* n) {
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+  for (int k = 0; k < NSLOT / 2; ++k) {
+    const uint32_t w = n[64 * k + lane];
+    army[2 * k] = (int32_t)(w & 0xFFFFu);
+    army[2 * k + 1] = (int32_t)(w >> 16);
+  }
+  if constexpr ((NSLOT & 1) != 0) army[NSLOT - 1] = (int32_t)reinterpret_cast<const uint16_t*>(n + 64 * (NSLOT / 2))[lane];
+}
+template <int NSLOT>
+__device__ __forceinline__ void army_load_wide(int32_t (&army)[NSLOT], const int32_t* w) {
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) army[s] = w[64 * s + lane];
+}
+// wave-uniform: every army of the board fits the narrow form (negative values have bit 31 set)
+template <int NSLOT>
+__device__ __forceinline__ bool army_fits_narrow(const int32_t (&army)[NSLOT]) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) m |= (uint32_t)army[s];
+  return __builtin_amdgcn_ballot_w64(m > 0xFFFFu) == 0ull;
+}
+template <int NSLOT>
+__device__ __forceinline__ void army_store_narrow(const int32_t (&army)[NSLOT], uint32_t* n) {
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+  for (int k = 0; k < NSLOT / 2; ++k) n[64 * k + lane] = (uint32_t)army[2 * k] | ((uint32_t)army[2 * k + 1] << 16);
+  if constexpr ((NSLOT & 1) != 0) reinterpret_cast<uint16_t*>(n + 64 * (NSLOT / 2))[lane] = (uint16_t)army[NSLOT - 1];
+}
+template <int NSLOT>
+__device__ __forceinline__ void army_store_wide(const int32_t (&army)[NSLOT], int32_t* w) {
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) w[64 * s + lane] = army[s];
+}
 
 // ---- wave primitives --------------------------------------------------------------------
 // NOTE: ds_bpermute / DPP read 0 from lanes that are masked off in EXEC.  Every cross-lane
@@ -103,6 +179,13 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
   v += dpp0<0x142, 0xa>(v);
   v += dpp0<0x143, 0xc>(v);
   return v;
+}
+// a * b + c on the low 24 bits of a and b, full rate.  Written as one instruction because the compiler
+// otherwise splits it into v_mul_u32_u24 + a shared v_add3 (2.5 instead of 2 instructions per term).
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -168,6 +251,9 @@ struct Board {
   // wave-uniform
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
+  // every army stays below 2^23 until the board is stored (true for one turn from a NARROW load): the
+  // masked sums may then use full-rate 24-bit multiply-adds.  Set by the kernel, never by load_*.
+  bool small = false;
 
   // ---- geometry masks of this board size ----------------------------------------------------
   __device__ __forceinline__ void geometry() {
@@ -211,7 +297,8 @@ struct Board {
     alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
   }
-  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (lane_id() == k) ? v : hv; }
+  // v must be wave-uniform (every caller passes scalar values): one v_writelane, no compare / select
+  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
 
   __device__ __forceinline__ void store_hdr(uint32_t* hdr_env, uint32_t last_err) {
@@ -267,15 +354,21 @@ struct Board {
 
   // whole 64-tile slots travel both ways (the padding beyond N holds zeros).  Trimming the store to
   // the board's N tiles was measured 4 % SLOWER: it turns the last slot into partial-line writes.
-  __device__ __forceinline__ void load_army(const int32_t* army_env) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) army[s] = army_env[64 * s + lane];
+  // The narrow block is read unconditionally (its loads need not wait for the header); a WIDE env
+  // - rare - reads its escape block on top.  Needs hflags: call after load_hdr.
+  __device__ __forceinline__ void load_army(const ArmyCRef& a) {
+    army_load_narrow<NSLOT>(army, a.n);
+    if (hflags & HF_WIDE) army_load_wide<NSLOT>(army, a.w);
   }
-  __device__ __forceinline__ void store_army(int32_t* army_env) const {
-    const int lane = lane_id();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) army_env[64 * s + lane] = army[s];
+  // Chooses the form (and sets / clears HF_WIDE in hflags accordingly): call BEFORE store_hdr.
+  __device__ __forceinline__ void store_army(const ArmyRef& a) {
+    if (army_fits_narrow<NSLOT>(army)) {
+      hflags &= ~HF_WIDE;
+      army_store_narrow<NSLOT>(army, a.n);
+    } else {
+      hflags |= HF_WIDE;
+      army_store_wide<NSLOT>(army, a.w);
+    }
   }
 
   // ---- uniform tile access ----------------------------------------------------------------
@@ -308,7 +401,10 @@ struct Board {
     const int lane = lane_id();
     return __builtin_amdgcn_sbfe((int32_t)bperm(((lane >> 5) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
-  __device__ __forceinline__ uint32_t gather(uint32_t plane, int s) const { return (uint32_t)gather_mask(plane, s) & 1u; }
+  __device__ __forceinline__ uint32_t gather(uint32_t plane, int s) const {
+    const int lane = lane_id();
+    return __builtin_amdgcn_ubfe(bperm(((lane >> 5) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
+  }
 
   // tile-domain predicates -> flat plane (the ballot of slot s is dwords 2s, 2s+1 of the bit string)
   __device__ __forceinline__ void scatter(uint32_t& plane, unsigned long long ballot, int s) const {
@@ -395,10 +491,18 @@ struct Board {
     int32_t acc[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) acc[p] = 0;
+    if (small) {  // bit * army + acc in one full-rate v_mad_u32_u24
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
+      for (int s = 0; s < NSLOT; ++s) {
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p], s);
+        for (int p = 0; p < MAXP; ++p) acc[p] = (int32_t)mad24((uint32_t)army[s], gather(lst[p], s), (uint32_t)acc[p]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p], s);
+      }
     }
     {  // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
       const int lane = lane_id();
@@ -437,7 +541,7 @@ struct Board {
     if (pg == pc && pc == an) {  // one rate for every producing tile: one gather per slot
       const uint32_t m = mg | mc | mn;
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s) army[s] += pg & gather_mask(m, s);
+      for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)(__umul24(gather(m, s), (uint32_t)pg) + (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
     } else {
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s)

@@ -99,7 +99,7 @@ __device__ __forceinline__ void agent_sample(const BT& b,
 // step / rollout kernel: `turns` engine turns per launch for one board per wavefront
 // =========================================================================================
 template <typename BT>
-__device__ __forceinline__ void load_board(BT& b, const uint32_t* hdr, const uint32_t* rows, const int32_t* army, int fd) {
+__device__ __forceinline__ void load_board(BT& b, const uint32_t* hdr, const uint32_t* rows, const ArmyCRef& army, int fd) {
   b.load_hdr(hdr);
   b.geometry();
   b.load_army(army);
@@ -113,7 +113,7 @@ __device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
   const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
   const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
-  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, A.pool_army + (size_t)j * NSLOT * 64, fd);
+  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, army_cref<NSLOT>(A.pool_army16, A.pool_army32, j), fd);
   b.hdr_set(H_EPISODE, episode);
   b.hdr_set(H_CNT_STEPS, cs);
   b.hdr_set(H_CNT_ABORT, ca);
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
+  bool force_redeal = false;
   if constexpr (!AGENT) {
     // GVEC_ACT_SKIP_ENV on player 0's action: this env sits the call out (nothing is read or
     // written; the host keeps the legal-mask buffer current for such calls)
@@ -184,23 +185,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
       if (A.err && lane == 0) A.err[env] = 0;
       return;
     }
+    force_redeal = (f0 & GVEC_ACT_RESET_ENV) != 0u;  // the caller ends this episode (truncation): re-deal now
   }
   B b;
   b.larmy = army_shadow[wave];
-  const size_t army_dw = (size_t)NSLOT * 64;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, A.army + (size_t)env * army_dw, FD);
+  const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD);
+  b.small = !(b.hflags & HF_WIDE);  // one turn from armies <= 65535: every sum of the turn stays below 2^23
   const bool emit = (A.flags & KF_EMIT) != 0u;
   uint32_t lm[MAXP][MPASS], okp[MPASS];
   uint32_t err = 0u;
   bool types_dirty = false, changed = true, okp_valid = false;
-  if (b.hflags & HF_DONE) {
-    if ((A.flags & KF_AUTORESET) && A.pool_size > 0) {
-      redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
-      types_dirty = true;
-    } else {
-      err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
-      changed = false;
-    }
+  const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
+  if (can_redeal && ((b.hflags & HF_DONE) || force_redeal)) {
+    redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
+    types_dirty = true;
+  } else if (b.hflags & HF_DONE) {
+    err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
+    changed = false;
   } else {
     uint32_t alo = 0u, ahi = 0u;
     if constexpr (AGENT) {
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
   }
+  b.store_army(army_env);  // picks the narrow / wide form: before the header, which records it
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
-  b.store_army(A.army + (size_t)env * army_dw);
   b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   if (env >= A.num_envs) return;
   B b;
   b.larmy = army_shadow[wave];
-  const size_t army_dw = (size_t)NSLOT * 64;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * army_dw, A.fd);
+  const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd);
   uint32_t lm[MAXP][MPASS];
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + n_steps);
   b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + n_abort);
   b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + n_done);
+  b.store_army(army_env);
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
-  b.store_army(A.army + (size_t)env * army_dw);
   b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   store_masks<MAXP, NSLOT>(lm, A, env);
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   uint32_t lm[MAXP][MPASS];
   if constexpr (MODE == 2) b.template legal_masks<true>(lm, A.fd);
   else b.template legal_masks<false>(lm, A.fd);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(Experien
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   uint32_t tail = 0u;  // lane p: territory, lane MAXP+p: armies, lane 2*MAXP: turn, +1: W|H<<8
 #pragma unroll
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(Experienc
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[MAXP * A.fd + lane] : 0u;
   const int prev_turn = (int)rdlane(tail, 2 * MAXP);
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const bool fog_on = (b.hflags & HF_FOG) != 0u;
   uint32_t own_any = 0u;
 #pragma unroll
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   }
   uint32_t* hdr = A.hdr + (size_t)env * HDR_DW;
   uint32_t* rows = A.rows + (size_t)env * A.row_dw;
-  int32_t* army = A.army + (size_t)env * NSLOT * 64;
+  const ArmyRef army = army_ref<NSLOT>(A.army16, A.army32, env);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
 
   B b;
@@ -609,8 +611,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     if (A.s_general_idx) b.hdr_set(H_GIDX + p, (uint32_t)A.s_general_idx[po + p]);
   }
   if (A.init) b.initial_setup();
-  b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_army(army);
+  b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_planes(rows, A.fd, A.row_dw, true);
 }
 
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
   const int env = A.env_begin + i;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, A.army + (size_t)env * NSLOT * 64, A.fd);
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
   const uint32_t special = b.gen | b.city | b.mtn;
   uint32_t pv_plane = 0u;
@@ -686,6 +688,63 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
       if (A.tile_count) A.tile_count[po + p] = live ? (int32_t)tcnt[p] : 0;
       if (A.general_idx) A.general_idx[po + p] = live ? (int32_t)b.hdr_get(H_GIDX + p) : -1;
     }
+  }
+}
+
+// =========================================================================================
+// resident records <-> canonical record slabs (gvec_export_records / gvec_import_records): a slab is
+// [n][HDR_DW] headers | [n][row_dw] planes | [n][NSLOT*64] int32 armies - always the wide form, whatever the
+// env's storage.  Import validates the header of every record before anything is trusted (a slab may come
+// from another rank or from a file).
+// =========================================================================================
+template <int MAXP, int NSLOT, bool IMPORT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArgs A) {
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.n) return;
+  const int env = A.env_begin + i;
+  uint32_t* rec_hdr = A.rec_hdr + (size_t)i * HDR_DW;
+  uint32_t* rec_rows = A.rec_rows + (size_t)i * A.row_dw;
+  int32_t* rec_army = A.rec_army + (size_t)i * NSLOT * 64;
+  B b;
+  b.larmy = nullptr;
+  if constexpr (!IMPORT) {
+    load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+    b.hflags &= ~HF_WIDE;
+    army_store_wide<NSLOT>(b.army, rec_army);
+    b.store_hdr(rec_hdr, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);
+    b.store_planes(rec_rows, A.fd, A.row_dw, true);
+  } else {
+    b.load_hdr(rec_hdr);
+    const bool bad = b.W < 1 || b.W > A.max_w || b.H < 1 || b.H > A.max_h || b.P < 1 || b.P > A.max_p || b.P > MAXP ||
+                     b.recipW != (65536 + (b.W > 0 ? b.W : 1) - 1) / (b.W > 0 ? b.W : 1) || (b.alive >> b.P) != 0u;
+    if (bad) {
+      if (lane == 0) atomicExch(A.status, GVEC_E_BOARD);
+      return;
+    }
+    b.hflags &= (HF_DONE | HF_FOG);
+    b.geometry();
+    army_load_wide<NSLOT>(b.army, rec_army);
+    b.load_planes(rec_rows, A.fd);
+    // nothing outside the board may be set: the turn logic relies on it
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const uint32_t keep = (p < b.P) ? b.valid : 0u;
+      b.own[p] &= keep;
+      b.lst[p] &= keep;
+      b.vis[p] &= keep;
+    }
+    b.chg &= b.valid;
+    b.vch &= b.valid;
+    b.gen &= b.valid;
+    b.city &= b.valid;
+    b.mtn &= b.valid;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) b.army[s] = (64 * s + lane < b.N) ? b.army[s] : 0;
+    b.store_army(army_ref<NSLOT>(A.army16, A.army32, env));
+    b.store_hdr(A.hdr + (size_t)env * HDR_DW, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);
+    b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   }
 }
 
@@ -967,6 +1026,14 @@ hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((export_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
                        0, s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_records(const Variant& v, const RecordArgs& a, bool import, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
+    if (import) hipLaunchKernelGGL((records_kernel<P, S, true>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((records_kernel<P, S, false>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }

@@ -17,7 +17,8 @@ bool pick_variant(int max_players, int tile_stride, Variant* out);
 struct ImportArgs {
   uint32_t* hdr;
   uint32_t* rows;
-  int32_t* army;
+  uint32_t* army16;  // narrow / wide army storage of the destination (gvec_device.hpp "army storage")
+  int32_t* army32;
   const int32_t* env_ids;  // [n] or null (env = dst_begin + i)
   int32_t dst_begin, n;
   // source planes, [n][stride] / [n][max_p] / [n]; null = keep current value
@@ -47,7 +48,8 @@ struct ImportArgs {
 struct ExportArgs {
   const uint32_t* hdr;
   const uint32_t* rows;
-  const int32_t* army;
+  const uint32_t* army16;
+  const int32_t* army32;
   int32_t env_begin, n;
   int32_t* army_out;
   int8_t* owner;
@@ -71,6 +73,19 @@ struct ExportArgs {
   uint8_t* pv_visible;
   uint8_t* pv_fog;
   int32_t stride, max_p, fd, row_dw;
+};
+
+// gvec_export_records / gvec_import_records: resident envs [env_begin, env_begin+n) <-> a record slab
+struct RecordArgs {
+  uint32_t* hdr;
+  uint32_t* rows;
+  uint32_t* army16;
+  int32_t* army32;
+  uint32_t* rec_hdr;   // [n][HDR_DW]
+  uint32_t* rec_rows;  // [n][row_dw]
+  int32_t* rec_army;   // [n][NSLOT*64], always int32
+  int32_t env_begin, n, fd, row_dw, max_w, max_h, max_p;
+  int32_t* status;
 };
 
 struct MapgenArgs {
@@ -100,7 +115,8 @@ hipError_t launch_serializer_mask(const Variant& v, const StepArgs& a, hipStream
 struct ExperienceArgs {
   const uint32_t* hdr;
   const uint32_t* rows;
-  const int32_t* army;
+  const uint32_t* army16;
+  const int32_t* army32;
   uint32_t* snap;     // [B][snap_dw]: prev own planes, territory[MAXP], armies[MAXP], turn, W|H<<8
   float* rewards;     // [B][pstride]
   uint8_t* done;      // [B] or null
@@ -112,6 +128,7 @@ hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s);
 hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s);
+hipError_t launch_records(const Variant& v, const RecordArgs& a, bool import, hipStream_t s);
 hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s);
 // sums the H_CNT_* counters of all envs into out[3] (u64, device)
 hipError_t launch_counter_sum(const uint32_t* hdr, int32_t num_envs, unsigned long long* out, hipStream_t s);

@@ -39,6 +39,7 @@ struct PBoard {
   int32_t* larmy;
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
+  bool small = false;  // see Board::small
 
   static __device__ __forceinline__ int col() { return lane_id() & (ROWL - 1); }
   static __device__ __forceinline__ int row() { return lane_id() / ROWL; }
@@ -115,7 +116,7 @@ struct PBoard {
     alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
   }
-  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (lane_id() == k) ? v : hv; }
+  __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
   __device__ __forceinline__ void store_hdr(uint32_t* hdr_env, uint32_t last_err) {
     hdr_set(H_TURN, (uint32_t)turn);
@@ -167,13 +168,19 @@ struct PBoard {
     }
     if (with_types && lane < row_dw - PL::MTN * fd) rows_env[PL::MTN * fd + lane] = (lane < fd) ? mtn : 0u;  // + the block's padding
   }
-  __device__ __forceinline__ void load_army(const int32_t* army_env) {
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) army[s] = army_env[64 * s + lane_id()];
+  // narrow (u16 pairs) / wide (int32 escape) army storage: see gvec_device.hpp "army storage"
+  __device__ __forceinline__ void load_army(const ArmyCRef& a) {
+    army_load_narrow<NSLOT>(army, a.n);
+    if (hflags & HF_WIDE) army_load_wide<NSLOT>(army, a.w);
   }
-  __device__ __forceinline__ void store_army(int32_t* army_env) const {
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) army_env[64 * s + lane_id()] = army[s];
+  __device__ __forceinline__ void store_army(const ArmyRef& a) {  // sets / clears HF_WIDE: call BEFORE store_hdr
+    if (army_fits_narrow<NSLOT>(army)) {
+      hflags &= ~HF_WIDE;
+      army_store_narrow<NSLOT>(army, a.n);
+    } else {
+      hflags |= HF_WIDE;
+      army_store_wide<NSLOT>(army, a.w);
+    }
   }
 
   // ---- LDS army shadow of the action phase (Board's) -----------------------------------------------
@@ -211,6 +218,10 @@ struct PBoard {
   __device__ __forceinline__ int32_t gather_mask(uint32_t plane, int s, int row_base = 0) const {
     const int lane = lane_id();
     return __builtin_amdgcn_sbfe((int32_t)bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
+  }
+  __device__ __forceinline__ uint32_t gather(uint32_t plane, int s, int row_base = 0) const {  // 0 / 1
+    const int lane = lane_id();
+    return __builtin_amdgcn_ubfe(bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
   // tile predicates -> flat plane: row 0 first (lane == constant: the selects take scalar masks, no vector
   // compares), then one ds_bpermute copies row 0 into every row
@@ -304,10 +315,19 @@ struct PBoard {
     int32_t acc[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) acc[p] = 0;
+    if (small) {  // bit * army + acc in one full-rate v_mad_u32_u24
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
+      for (int s = 0; s < NSLOT; ++s) {
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
+        for (int p = 0; p < MAXP; ++p)
+          acc[p] = (int32_t)mad24((uint32_t)army[s], gather(lst[p / PPR], s, (p % PPR) * ROWL), (uint32_t)acc[p]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
+      }
     }
     {
       const int lane = lane_id();
@@ -354,7 +374,7 @@ struct PBoard {
     if (pg == pc && pc == an) {
       const uint32_t m = mg | mc | mn;
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s) army[s] += pg & gather_mask(m, s);
+      for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)(__umul24(gather(m, s), (uint32_t)pg) + (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
     } else {
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) army[s] += (pg & gather_mask(mg, s)) + (pc & gather_mask(mc, s)) + (pn & gather_mask(mn, s));

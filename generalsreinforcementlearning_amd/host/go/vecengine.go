@@ -142,10 +142,32 @@ func (e *VecEngine) Step(actions [][]core.Action) ([]error, error) {
 		return nil, err
 	}
 	out := make([]error, len(e.errs))
+	var turns []int32 // read back only when some env failed: the reference's message carries gs.Turn
 	for i, code := range e.errs {
-		if code != 0 {
-			out[i] = core.WrapGameStateError(0, "action processing", sentinels[int32(code)])
+		if code == 0 {
+			continue
 		}
+		if turns == nil {
+			turns = make([]int32, len(e.errs))
+			var v C.gvec_state_view
+			v.turn = (*C.int32_t)(unsafe.Pointer(&turns[0]))
+			if err := apiErr(C.gvec_read_state(e.h, 0, C.int32_t(len(e.errs)), &v, C.GVEC_MEM_HOST), "gvec_read_state"); err != nil {
+				return nil, err
+			}
+		}
+		s := sentinels[int32(code)]
+		if code == 5 {
+			// TurnProcessor.validateGameState (turn_processor.go:95-113): a finished engine refuses the turn.
+			// (A naturally finished game trips the phase check first in Go and returns an unwrapped
+			// "game is in ... phase" error; both are reported as ErrGameOver here.)
+			out[i] = core.WrapGameStateError(int(turns[i]), "step", s)
+			continue
+		}
+		// Engine.processActions wraps the first move error with the (already incremented) turn (engine.go:111-113),
+		// TurnProcessor.processActionsPhase wraps that again (turn_processor.go:143-156).  The innermost
+		// core.WrapActionError text (which move failed) is not reproduced: errors.Is sees the same sentinel.
+		out[i] = core.WrapGameStateError(int(turns[i]), "action processing",
+			core.WrapGameStateError(int(turns[i]), "processing actions", s))
 	}
 	return out, nil
 }

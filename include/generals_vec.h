@@ -84,6 +84,11 @@ extern "C" {
                                mirror clients whose games advance at different times
                                (python/generals_gym/generals_env.py:226-241 returns
                                before submitting anything on an invalid action).         */
+#define GVEC_ACT_RESET_ENV 8u /* on actions[env][0] only, handles with auto_reset and a board pool: this env
+                                is re-dealt from the pool in this call whether or not its game is over
+                                (err 0) - how a vector env ends a truncated episode
+                                (generals_env.py:283-284: truncated = turn_count >= max_turns) without
+                                reading `done` back and poking it.  Ignored without a pool.          */
 typedef struct gvec_action {
   int8_t  from_x, from_y, to_x, to_y;
   uint8_t flags;
@@ -155,7 +160,7 @@ const char* gvec_last_error(void);
 int32_t gvec_num_envs(const gvec_handle* h);
 int32_t gvec_tile_stride(const gvec_handle* h);   /* max_width*max_height              */
 int32_t gvec_mask_bytes(const gvec_handle* h);    /* bytes of one player's packed mask: 4 direction bit-planes (see gvec_step) */
-int64_t gvec_state_bytes_per_env(const gvec_handle* h); /* resident device bytes / env */
+int64_t gvec_state_bytes_per_env(const gvec_handle* h); /* bytes of one env's state record (gvec_export_records) */
 
 /* ---- reset: EngineInitializer.Initialize minus mapgen -------------------------
  * (engine_initializer.go:113-143,218-225): upload boards, Turn=0, then the a15
@@ -263,22 +268,29 @@ int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
 
 /* ---- experience gather support ---------------------------------------
- * Copies the compact resident records of envs [env_begin, env_begin+n) into a
- * device buffer (e.g. a torch tensor handed to RCCL all_gather).  Record size:
- * gvec_state_bytes_per_env(). */
+ * Writes the compact state records of envs [env_begin, env_begin+n) into a device
+ * buffer (e.g. a torch tensor handed to RCCL) as a slab [n] headers | [n] plane blocks |
+ * [n] int32 army blocks: gvec_state_bytes_per_env() bytes per env.  Armies are always
+ * int32 in a record, whatever form the env is stored in.  gvec_import_records checks
+ * every record header against the handle's limits (board size, player count, reciprocal)
+ * on the device and fails with GVEC_E_BOARD - that env left untouched - on a mismatch. */
 int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n,
                             void* dst_device);
 int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n,
                             const void* src_device);
 /* Zero-copy access for device consumers (torch-ROCm): the handle's resident device
- * arrays.  which: 0 header [B][24] u32, 1 bit-rows, 2 armies, 3 legal masks
- * [B][max_players][mask_bytes], 4 actions [B][max_players], 5 err [B]. */
+ * arrays.  which: 0 header [B][24] u32, 1 bit-planes, 2 armies (narrow form: u16, two 64-tile slots
+ * interleaved per dword; authoritative for every env whose header flag bit 2 is clear - see
+ * DESIGN.md section 3), 6 armies (wide form: int32, authoritative for the flagged envs), 3 legal masks
+ * [B][max_players][mask_bytes], 4 actions [B][max_players], 5 err [B].  Consumers that want plain
+ * per-tile planes use gvec_read_state with GVEC_MEM_DEVICE instead. */
 #define GVEC_BUF_HEADER  0
 #define GVEC_BUF_ROWS    1
 #define GVEC_BUF_ARMY    2
 #define GVEC_BUF_LEGAL   3
 #define GVEC_BUF_ACTIONS 4
 #define GVEC_BUF_ERR     5
+#define GVEC_BUF_ARMY_WIDE 6
 void*   gvec_device_buffer(gvec_handle* h, int32_t which);
 
 /* Runs the on-device self-test of the wave primitives (DPP shifts, scans,

@@ -606,7 +606,9 @@ int32_t ora_batch_step(ora_batch* b, const ora_action8* actions, int32_t* err, u
     if (!b->env[id]) { if (err) err[id] = -1; continue; }
     int32_t rc;
     if (actions[(size_t)id * (size_t)b->max_p].flags & 4u) rc = 0;   /* GVEC_ACT_SKIP_ENV: sits this call out */
-    else if (b->pool_size > 0 && b->env[id]->game_over) { redeal_env(b, id); rc = 0; }
+    else if (b->pool_size > 0 && (b->env[id]->game_over || (actions[(size_t)id * (size_t)b->max_p].flags & 8u))) {
+      redeal_env(b, id); rc = 0;   /* finished, or GVEC_ACT_RESET_ENV: the caller ends the episode */
+    }
     else rc = step_env(b, id, actions + (size_t)id * (size_t)b->max_p);
     if (err) err[id] = rc;
     if (legal_bits) {
