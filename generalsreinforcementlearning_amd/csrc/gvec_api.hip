@@ -229,6 +229,7 @@ int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* a
   a.fog = h->cfg.fog_of_war ? 1u : 0u;
   a.status = h->d_status;
   HIPCHK(launch_import(h->var, a, h->stream));
+  if (init) HIPCHK(launch_setup(h->var, a, h->stream));
   return GVEC_OK;
 }
 
@@ -327,7 +328,7 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   }
   // dwords per flat bit-plane: 2*nslot-1 or 2*nslot, so that the step kernel can be compiled for it
   h->fd = (h->stride <= 32 * (2 * h->var.nslot - 1)) ? 2 * h->var.nslot - 1 : 2 * h->var.nslot;
-  h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 5) * h->fd, 4);
+  h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 13) * h->fd, 4);  // Planes<MAXP>::COUNT planes of fd dwords
   h->army_dw = h->var.nslot * 64;
   h->mask_bytes = 16 * h->fd;  // four direction bit-planes of fd dwords per player
   h->mask_dw = h->mask_bytes / 4;

@@ -17,9 +17,19 @@
 //     A flat plane reaches the tile domain with one ds_bpermute (dword 2s + (l>>5)) and a
 //     bit-field extract at bit l&31: no per-tile coordinates are ever computed.
 //
+//       gt1     Tile.Army > 1 of the resident state (the army-dependent half of every legal-move
+//               predicate: stored so the next launch need not rebuild it from the armies)
+//       valid / ncol0 / ncolL / ok[4]   geometry masks and "the d-neighbour is on the board and not a
+//               mountain": functions of the board size and the type planes only, computed once when a
+//               board is imported and carried as constant planes (loading 364 bytes costs less than
+//               the ~55 vector instructions that rebuild them: the step kernel is VALU-issue bound)
+//
 // Planes and armies are loaded straight into registers (plane p: lane i reads dword i; armies:
 // 256 B per wave instruction); the planes block of one env is a contiguous, 16-byte aligned run.  Integer / bit work only: no MFMA
 // anywhere (HBM-roofline kernel).
+//
+// This file holds the PLAIN layout (`Board`: one register per plane, used by the conversion and experience
+// kernels) and everything both layouts share; the turn logic lives in gvec_packed.hpp (`PBoard`).
 //
 // Every routine cites the Go function it reproduces (paths relative to
 // /root/reference/internal/game/).  Semantics are the plane re-statement derived in
@@ -54,12 +64,15 @@ enum : int {
   H_CNT_DONE = 23
 };
 constexpr uint32_t HF_DONE = 1u, HF_FOG = 2u, HF_WIDE = 4u;
+constexpr uint32_t HF_SETUP = 8u;  // transient: imported with init, performInitialSetup still to run (setup_kernel clears it)
 
-// plane order inside the planes block; the last three never change after reset
+// plane order inside the planes block; the planes from GEN on never change after a board is imported
 template <int MAXP>
 struct Planes {
-  static constexpr int OWN = 0, LST = MAXP, VIS = 2 * MAXP, CHG = 3 * MAXP, VCH = 3 * MAXP + 1, GEN = 3 * MAXP + 2,
-                       CITY = 3 * MAXP + 3, MTN = 3 * MAXP + 4, COUNT = 3 * MAXP + 5, MUTABLE = 3 * MAXP + 2;
+  static constexpr int OWN = 0, LST = MAXP, VIS = 2 * MAXP, CHG = 3 * MAXP, VCH = 3 * MAXP + 1, GT1 = 3 * MAXP + 2,
+                       GEN = 3 * MAXP + 3, CITY = 3 * MAXP + 4, MTN = 3 * MAXP + 5, VALID = 3 * MAXP + 6, NCOL0 = 3 * MAXP + 7,
+                       NCOLL = 3 * MAXP + 8, OK = 3 * MAXP + 9 /* [4]: up, right, down, left */, COUNT = 3 * MAXP + 13,
+                       MUTABLE = 3 * MAXP + 3;
 };
 
 constexpr uint32_t KF_AGENT = 1u;      // sample actions on device instead of reading them
@@ -232,30 +245,29 @@ struct ColumnPatternTable {
 __device__ const ColumnPatternTable kColumnPattern{};
 
 // =========================================================================================
+// Board: the PLAIN register layout - one register per (plane kind, player); lane i holds dword i of the bit
+// string.  Used by the kernels that convert between the resident record and per-tile planes (import /
+// export / records) and by the experience kernels; it owns the routines that BUILD the constant planes.
+// =========================================================================================
 template <int MAXP, int NSLOT>
 struct Board {
   using PL = Planes<MAXP>;
-  static constexpr int MPASS = (NSLOT > 8) ? 2 : 1;  // legal-mask dwords per lane (8 tiles each)
 
   // flat domain
-  uint32_t own[MAXP], lst[MAXP], vis[MAXP], chg, vch, gen, city, mtn;
+  uint32_t own[MAXP], lst[MAXP], vis[MAXP], chg, vch, gt1, gen, city, mtn;
   uint32_t valid;  // bits t < N
   uint32_t ncol0;  // bits with x != 0      (guards a shift towards higher t)
   uint32_t ncolL;  // bits with x != W - 1  (guards a shift towards lower t)
+  uint32_t ok[4];  // the neighbour in direction d (0 up, 1 right, 2 down, 3 left) is on the board and not a mountain
   // tile domain
   int32_t army[NSLOT];
-  // header: lane k holds header dword k (Player.ArmyCount / GeneralIdx, counters, ... live here;
-  // only what the turn logic branches on is also kept wave-uniform below)
+  // header: lane k holds header dword k
   uint32_t hv;
-  int32_t* larmy;  // LDS shadow of the armies during the action phase: tile t at larmy[t]
   // wave-uniform
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
-  // every army stays below 2^23 until the board is stored (true for one turn from a NARROW load): the
-  // masked sums may then use full-rate 24-bit multiply-adds.  Set by the kernel, never by load_*.
-  bool small = false;
 
-  // ---- geometry masks of this board size ----------------------------------------------------
+  // ---- geometry masks of this board size (computed on import, then carried as planes) ---------
   __device__ __forceinline__ void geometry() {
     const int t0 = 32 * (lane_id() & 31);
     const int left = N - t0;
@@ -267,6 +279,23 @@ struct Board {
     const uint32_t col0 = pat << (x0 ? W - x0 : 0);
     ncol0 = ~col0;
     ncolL = ~__builtin_amdgcn_alignbit(from_next(col0), col0, 1);  // t is in the last column iff t+1 is in column 0
+    ncol0 = (lane_id() < 32) ? ncol0 : 0xFFFFFFFFu;                // lanes beyond the bit string hold no tiles: any value
+    ncolL = (lane_id() < 32) ? ncolL : 0xFFFFFFFFu;                // would do, a fixed one keeps the stored planes canonical
+  }
+  // the player-independent half of MoveAction.Validate (core/action.go:58-64, :96-98) per direction,
+  // rules/legal_moves.go:13-18 order: needs geometry() and the type planes
+  __device__ __forceinline__ void targets() {
+    const uint32_t notm = ~mtn & valid;
+    ok[0] = upW(notm);          // target (x, y-1)
+    ok[1] = dn1(notm) & ncolL;  // target (x+1, y)
+    ok[2] = dnW(notm);          // target (x, y+1)
+    ok[3] = up1(notm) & ncol0;  // target (x-1, y)
+  }
+  // Tile.Army > 1 as a flat plane
+  __device__ __forceinline__ void refresh_gt1() {
+    gt1 = 0u;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
   }
 
   // ---- flat-string shifts: bit t of the result = bit (t -+ k) of m ---------------------------
@@ -278,10 +307,6 @@ struct Board {
   __device__ __forceinline__ uint32_t dnW(uint32_t m) const {  // from t+W
     return (uint32_t)((((uint64_t)from_next(m) << 32) | (uint64_t)m) >> W);
   }
-  __device__ __forceinline__ uint32_t dil_h(uint32_t m) const { return m | (up1(m) & ncol0) | (dn1(m) & ncolL); }
-  __device__ __forceinline__ uint32_t dil_v(uint32_t m) const { return (m | upW(m) | dnW(m)) & valid; }
-  // 3x3 / 5x5 neighbourhoods (visibility_optimized.go:9-13, :104-105)
-  __device__ __forceinline__ uint32_t dil3(uint32_t m) const { return dil_v(dil_h(m)); }
 
   // ---- load / store ---------------------------------------------------------------------
   __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
@@ -310,28 +335,34 @@ struct Board {
     if (lane < HDR_DW) hdr_env[lane] = hv;
   }
 
-  // planes: lane i holds dword i of each bit string.  Staging the block through LDS with dwordx4
-  // copies was measured 4 % slower (the LDS pipe is as busy as the VALU in this kernel).
   __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd) {
     const int lane = lane_id();
     const bool on = lane < fd;
     const uint32_t* g = rows_env + (on ? lane : 0);
+    auto ld = [&](int plane) {
+      const uint32_t v = g[plane * fd];
+      return on ? v : 0u;
+    };
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-      uint32_t a = g[(PL::OWN + p) * fd], b = g[(PL::LST + p) * fd], c = g[(PL::VIS + p) * fd];
-      own[p] = on ? a : 0u;
-      lst[p] = on ? b : 0u;
-      vis[p] = on ? c : 0u;
+      own[p] = ld(PL::OWN + p);
+      lst[p] = ld(PL::LST + p);
+      vis[p] = ld(PL::VIS + p);
     }
-    uint32_t a = g[PL::CHG * fd], b = g[PL::VCH * fd], c = g[PL::GEN * fd], d = g[PL::CITY * fd], e = g[PL::MTN * fd];
-    chg = on ? a : 0u;
-    vch = on ? b : 0u;
-    gen = on ? c : 0u;
-    city = on ? d : 0u;
-    mtn = on ? e : 0u;
+    chg = ld(PL::CHG);
+    vch = ld(PL::VCH);
+    gt1 = ld(PL::GT1);
+    gen = ld(PL::GEN);
+    city = ld(PL::CITY);
+    mtn = ld(PL::MTN);
+    valid = ld(PL::VALID);
+    ncol0 = ld(PL::NCOL0);
+    ncolL = ld(PL::NCOLL);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ok[d] = ld(PL::OK + d);
   }
 
-  // The type planes change only when the env is re-dealt (with_types).
+  // The planes from GEN on change only when a board is imported or re-dealt (with_types).
   __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
     const int lane = lane_id();
     if (lane < fd) {
@@ -344,16 +375,23 @@ struct Board {
       }
       g[PL::CHG * fd] = chg;
       g[PL::VCH * fd] = vch;
+      g[PL::GT1 * fd] = gt1;
       if (with_types) {
         g[PL::GEN * fd] = gen;
         g[PL::CITY * fd] = city;
+        g[PL::MTN * fd] = mtn;
+        g[PL::VALID * fd] = valid;
+        g[PL::NCOL0 * fd] = ncol0;
+        g[PL::NCOLL * fd] = ncolL;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[(PL::OK + d) * fd] = ok[d];
       }
     }
-    if (with_types && lane < row_dw - PL::MTN * fd) rows_env[PL::MTN * fd + lane] = mtn;  // lanes >= fd hold 0: the padding
+    // the last plane and the block's padding in one store (lanes >= fd write zeros)
+    if (with_types && lane < row_dw - (PL::OK + 3) * fd) rows_env[(PL::OK + 3) * fd + lane] = (lane < fd) ? ok[3] : 0u;
   }
 
-  // whole 64-tile slots travel both ways (the padding beyond N holds zeros).  Trimming the store to
-  // the board's N tiles was measured 4 % SLOWER: it turns the last slot into partial-line writes.
+  // whole 64-tile slots travel both ways (the padding beyond N holds zeros).
   // The narrow block is read unconditionally (its loads need not wait for the header); a WIDE env
   // - rare - reads its escape block on top.  Needs hflags: call after load_hdr.
   __device__ __forceinline__ void load_army(const ArmyCRef& a) {
@@ -371,30 +409,7 @@ struct Board {
     }
   }
 
-  // ---- uniform tile access ----------------------------------------------------------------
-  // During the action phase the armies live in an LDS shadow: a wave-uniform tile index is one
-  // broadcast ds_read / one single-lane ds_write instead of an NSLOT-way register select chain
-  // (which costs ~3 scalar instructions per slot on the CU's single scalar pipe).
-  __device__ __forceinline__ void army_to_lds() {
-    const int lane = lane_id();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) larmy[64 * s + lane] = army[s];
-    wave_lds_fence();
-  }
-  __device__ __forceinline__ void army_from_lds() {
-    const int lane = lane_id();
-    wave_lds_fence();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) army[s] = larmy[64 * s + lane];
-  }
-  __device__ __forceinline__ int army_get(int t) const { return uni(larmy[t]); }
-  __device__ __forceinline__ void army_set(int t, int val) {
-    if (lane_id() == 0) larmy[t] = val;
-  }
-  __device__ __forceinline__ bool bit_at(uint32_t plane, int t) const { return (rdlane(plane, t >> 5) >> (t & 31)) & 1u; }
-  // the single bit of tile t as a flat plane
-  __device__ __forceinline__ uint32_t tile_bit(int t) const { return (lane_id() == (t >> 5)) ? (1u << (t & 31)) : 0u; }
-
+  // ---- flat <-> tile domain ------------------------------------------------------------------
   // tile-domain all-ones / zero mask (gather_mask) or 0/1 (gather) of a flat plane: tile 64s+l is
   // bit l&31 of dword 2s + (l>>5)
   __device__ __forceinline__ int32_t gather_mask(uint32_t plane, int s) const {
@@ -405,366 +420,10 @@ struct Board {
     const int lane = lane_id();
     return __builtin_amdgcn_ubfe(bperm(((lane >> 5) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
-
   // tile-domain predicates -> flat plane (the ballot of slot s is dwords 2s, 2s+1 of the bit string)
   __device__ __forceinline__ void scatter(uint32_t& plane, unsigned long long ballot, int s) const {
-    const int lane = lane_id();
-    plane = (lane == 2 * s) ? (uint32_t)ballot : plane;
-    plane = (lane == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
-  }
-
-  // ---- Engine.updateFogOfWarOptimized (visibility_optimized.go:16-97) --------------------
-  __device__ __forceinline__ void update_fog() {
-    if (!(hflags & HF_FOG)) return;  // :17-19
-    const int nv = (int)wave_sum(__builtin_popcount(vch));
-    if (turn == 0 || nv > N / 10) {  // :22-26 full: clear, then 3x3 around every listed tile of alive players (:33-53)
-#pragma unroll
-      for (int p = 0; p < MAXP; ++p) {
-        const uint32_t d = dil3(lst[p]);  // cross-lane: outside the (uniform) select
-        vis[p] = ((alive >> p) & 1u) ? d : 0u;
-      }
-      return;
-    }
-    if (nv == 0) return;  // incremental update over an empty set is the identity
-    // :56-97 affected = board owners within 5x5 of V (:100-116); clear all players in 3x3 of V
-    // (:132-150); re-light affected, alive players from their lists (:85-94)
-    const uint32_t near3 = dil3(vch), near5 = dil3(near3), clr = ~near3;
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      const bool relight = wave_any((own[p] & near5) != 0u) && ((alive >> p) & 1u);
-      uint32_t v = vis[p] & clr;
-      if (relight) v |= dil3(lst[p]);  // wave-uniform branch
-      vis[p] = v;
-    }
-  }
-
-  // Wave-wide sums of MAXP per-lane accumulators in ONE reduction tree (a tree per player costs 6 DPP
-  // adds each).  First the accumulators are folded into one register, lane l keeping class
-  // l & (MAXP-1): at each level a lane keeps its own class's half and hands the other half to its
-  // partner (quad_perm / row_ror swaps).  Then lanes of equal class are summed: row_shr inside a row of
-  // 16, ds_swizzle (xor 16) and ds_bpermute (xor 32) across rows.  Returns a register whose lanes
-  // H_ARMYCNT+p hold the total of acc[p].
-  __device__ __forceinline__ uint32_t multi_sum(const int32_t (&acc)[MAXP]) const {
-    static_assert(MAXP == 2 || MAXP == 4 || MAXP == 8, "fold levels are written for 2, 4 or 8 players");
-    static_assert(H_ARMYCNT == 4, "the final row_shl assumes header lanes 4..4+MAXP-1");
-    const int lane = lane_id();
-    uint32_t m[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) m[p] = (uint32_t)acc[p];
-    {
-      const bool hi = (lane & 1) != 0;
-#pragma unroll
-      for (int i = 0; i < MAXP / 2; ++i) {
-        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
-        m[i] = keep + dpp0<0xB1>(give);  // quad_perm [1,0,3,2]
-      }
-    }
-    if constexpr (MAXP >= 4) {
-      const bool hi = (lane & 2) != 0;
-#pragma unroll
-      for (int i = 0; i < MAXP / 4; ++i) {
-        const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
-        m[i] = keep + dpp0<0x4E>(give);  // quad_perm [2,3,0,1]
-      }
-    }
-    if constexpr (MAXP >= 8) {
-      const bool hi = (lane & 4) != 0;
-      const uint32_t keep = hi ? m[1] : m[0], give = hi ? m[0] : m[1];
-      m[0] = keep + dpp0<0x124>(give);  // row_ror:4 (the partner differs in bit 2; a bijection is all a sum needs)
-    }
-    uint32_t r = m[0];
-    if constexpr (MAXP <= 2) r += dpp0<0x112>(r);  // row_shr:2
-    if constexpr (MAXP <= 4) r += dpp0<0x114>(r);  // row_shr:4
-    r += dpp0<0x118>(r);                           // row_shr:8 -> the last MAXP lanes of each row hold the row's sums
-    r += (uint32_t)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);  // lane ^ 16
-    r += bperm((lane ^ 32) << 2, r);
-    return dpp0<0x100 + 12 - MAXP>(r);  // row_shl: lanes 16-MAXP.. of row 0 -> lanes 4..
-  }
-
-  // ---- Engine.updatePlayerStats (stats.go:8-144) -------------------------------------------
-  __device__ __forceinline__ void update_stats() {
-    const int nc = (int)wave_sum(__builtin_popcount(chg));
-    if (nc == 0 && turn > 0) return;             // :10-14
-    const bool full = turn == 0 || nc > N / 5;  // :20-21
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) lst[p] = full ? own[p] : (own[p] & (lst[p] | chg));  // :33-49 / :90-130
-    int32_t acc[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) acc[p] = 0;
-    if (small) {  // bit * army + acc in one full-rate v_mad_u32_u24
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) acc[p] = (int32_t)mad24((uint32_t)army[s], gather(lst[p], s), (uint32_t)acc[p]);
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p], s);
-      }
-    }
-    {  // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
-      const int lane = lane_id();
-      const uint32_t tot = multi_sum(acc);
-      hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
-    }
-    alive = 0u;
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two
-      // or more generals that order depends on Go map iteration.  Here: the highest tile index.
-      const uint32_t g = lst[p] & gen;
-      const unsigned long long dw = __builtin_amdgcn_ballot_w64(g != 0u);
-      int gi = -1;
-      if (dw) {
-        const int i = 63 - __builtin_clzll(dw);
-        gi = 32 * i + (31 - __builtin_clz(rdlane(g, i)));
-      }
-      hdr_set(H_GIDX + p, (uint32_t)gi);
-      alive |= (gi >= 0) ? (1u << p) : 0u;  // :52-54 / :133-135
-    }
-  }
-
-  // ---- ProductionManager.ProcessTurnProduction (production_manager.go:26-101) -------------
-  __device__ __forceinline__ void production(int pg, int pc, int pn, int interval) {
-    const bool grow = (turn % interval) == 0;  // :27
-    uint32_t listed_alive = 0u;                // :39-45: lists of alive players, owner NOT re-checked (H7)
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) listed_alive |= ((alive >> p) & 1u) ? lst[p] : 0u;
-    const uint32_t normal = ~(gen | city | mtn) & valid;
-    const uint32_t mg = (pg > 0) ? (listed_alive & gen) : 0u;
-    const uint32_t mc = (pc > 0) ? (listed_alive & city) : 0u;
-    const uint32_t mn = (grow && pn > 0) ? (listed_alive & normal) : 0u;
-    chg |= mg | mc | mn;  // :59-61 (prod > 0 only)
-    const int an = (grow && pn > 0) ? pn : pc;
-    if (pg == pc && pc == an) {  // one rate for every producing tile: one gather per slot
-      const uint32_t m = mg | mc | mn;
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)(__umul24(gather(m, s), (uint32_t)pg) + (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
-    } else {
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s)
-        army[s] += (pg & gather_mask(mg, s)) + (pc & gather_mask(mc, s)) + (pn & gather_mask(mn, s));
-    }
-  }
-
-  // ---- WinConditionChecker.CheckGameOver (rules/win_conditions.go:21-57) -------------------
-  __device__ __forceinline__ void check_game_over() {
-    const int na = __builtin_popcount(alive);
-    const bool over = (P > 1) ? (na <= 1) : (na == 0);  // originalPlayers == len(Players)
-    hflags = over ? (hflags | HF_DONE) : (hflags & ~HF_DONE);
-    // the winner is re-derived from Alive on read-back, like Engine.GetWinner (engine.go:248-263)
-  }
-
-  // ---- the action phase: ActionProcessor.ProcessActions (processor/action_processor.go:36-99) ----
-  // Everything about a move that does not depend on the board as modified by lower player ids is
-  // computed for all players at once on lanes (lane p = player p): coordinate unpack, bounds,
-  // same-tile and adjacency checks of MoveAction.Validate (core/action.go:58-76), tile indices.
-  struct ActVec {
-    uint32_t meta;  // bits 0-3 static Validate code, bit 4 present (non-nil), bit 5 half
-    int ft, tt;     // y*W + x of source / target
-  };
-  __device__ __forceinline__ ActVec prevalidate(uint32_t alo, uint32_t ahi) const {
-    ActVec v;
-    const int fx = (int)(int8_t)(alo & 0xFFu), fy = (int)(int8_t)((alo >> 8) & 0xFFu);
-    const int tx = (int)(int8_t)((alo >> 16) & 0xFFu), ty = (int)(int8_t)(alo >> 24);
-    const bool inb = fx >= 0 && fx < W && fy >= 0 && fy < H && tx >= 0 && tx < W && ty >= 0 && ty < H;
-    const int dx = fx - tx, dy = fy - ty;
-    const int md = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
-    uint32_t code = 0u;
-    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;      // action.go:72-76 (orthogonal, one step)
-    code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;      // :67-69
-    code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;  // :58-64
-    v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
-    v.ft = __mul24(fy, W) + fx;  // |coordinates| < 128: full-rate 24-bit multiply
-    v.tt = __mul24(ty, W) + tx;
-    return v;
-  }
-
-  // The state-dependent rest of Validate + core.ApplyMoveAction (core/movement.go:23-89) for
-  // player PID, wave-uniform.  `orders` packs core.ProcessCaptures' output (movement.go:100-118):
-  // byte k = victim | new_owner << 4.
-  template <int PID>
-  __device__ __forceinline__ void apply_action(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
-                                               uint32_t& elim_seen) {
-    const uint32_t m = rdlane(av.meta, PID);
-    if (!(m & 16u)) return;              // nil action
-    if (!((alive >> PID) & 1u)) return;  // action_processor.go:56-60 (Alive as last written, H2)
-    uint32_t code = m & 15u;
-    int fa = 0, ta = 0, ft = 0, tt = 0;
-    if (!code) {
-      ft = (int)rdlane((uint32_t)av.ft, PID);
-      tt = (int)rdlane((uint32_t)av.tt, PID);
-      fa = army_get(ft);
-      ta = army_get(tt);
-      if (!bit_at(own[PID], ft)) code = GVEC_ERR_NOT_OWNED;          // action.go:82-84
-      else if (fa <= 1) code = GVEC_ERR_INSUFFICIENT_ARMY;           // :87-89
-      else if (bit_at(mtn, tt)) code = GVEC_ERR_TARGET_IS_MOUNTAIN;  // :96-98
-    }
-    if (code) {  // action_processor.go:66-77: remember the FIRST error, keep going
-      first_err = first_err ? first_err : code;
-      return;
-    }
-    int n = (m & 32u) ? (fa / 2) : (fa - 1);  // movement.go:40-49
-    n = (n == 0) ? 1 : n;
-    const uint32_t fbit = tile_bit(ft), tbit = tile_bit(tt);
-    army_set(ft, fa - n);  // :54
-    chg |= fbit | tbit;    // :57-60
-    if (bit_at(own[PID], tt)) {  // :62-66 own tile: consolidate
-      army_set(tt, ta + n);
-    } else if (n > ta) {  // :69-82 capture (ties favour the defender)
-      int prev = -1;
-#pragma unroll
-      for (int q = 0; q < MAXP; ++q) {
-        if (bit_at(own[q], tt)) prev = q;
-        own[q] &= ~tbit;
-      }
-      own[PID] |= tbit;
-      army_set(tt, n - ta);
-      vch |= tbit;  // action_processor.go:84-86
-      // movement.go:105-108
-      if (bit_at(gen, tt) && prev >= 0 && !((elim_seen >> prev) & 1u)) {
-        orders |= (uint64_t)((uint32_t)prev | ((uint32_t)PID << 4)) << (8 * n_orders);
-        n_orders++;
-        elim_seen |= 1u << prev;
-      }
-    } else {
-      army_set(tt, ta - n);  // :85
-    }
-  }
-
-  template <int PID>
-  __device__ __forceinline__ void act_chain(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
-                                            uint32_t& elim_seen) {
-    if constexpr (PID < MAXP) {
-      if (PID < P) apply_action<PID>(av, first_err, orders, n_orders, elim_seen);
-      act_chain<PID + 1>(av, first_err, orders, n_orders, elim_seen);
-    }
-  }
-
-  // ---- Engine.handleEliminationsAndTileTurnover (engine.go:118-152) -------------------------
-  __device__ __forceinline__ void eliminate(uint64_t orders, int n_orders) {
-    for (int k = 0; k < n_orders; ++k) {
-      const int v = (int)((orders >> (8 * k)) & 15u), nw = (int)((orders >> (8 * k + 4)) & 15u);
-      uint32_t tiles = 0u;  // victim's listed tiles still owned by the victim (:130-131, H4)
-#pragma unroll
-      for (int q = 0; q < MAXP; ++q) tiles |= (q == v) ? (lst[q] & own[q]) : 0u;
-#pragma unroll
-      for (int q = 0; q < MAXP; ++q) {
-        own[q] = (q == v) ? (own[q] & ~tiles) : own[q];
-        own[q] = (q == nw) ? (own[q] | tiles) : own[q];
-      }
-      hdr_set(H_GIDX + v, 0xFFFFFFFFu);  // :141 GeneralIdx = -1
-      chg |= tiles;                      // :133-134
-      vch |= tiles;
-      alive &= ~(1u << v);  // :140
-    }
-  }
-
-  // ---- TurnProcessor.ProcessTurn (turn_processor.go:29-77) ----------------------------------
-  // acts_lo/hi: lane p holds player p's gvec_action words.  Returns the per-env error code.
-  // Precondition: the caller has checked Engine.gameOver (validateGameState :95-113).
-  __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, bool& aborted) {
-    aborted = false;
-    turn++;  // initializeTurn :124-135
-    update_fog();
-    chg = 0u;
-    vch = 0u;
-    uint32_t first_err = 0u, elim_seen = 0u;
-    uint64_t orders = 0ull;
-    int n_orders = 0;
-    // Engine.processActions (engine.go:80-115): PlayerID order == slot order (sort.Slice :39-41)
-    const ActVec av = prevalidate(acts_lo, acts_hi);
-    const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
-    if (present) {  // a turn where nobody moves touches no army
-      army_to_lds();
-      act_chain<0>(av, first_err, orders, n_orders, elim_seen);
-      army_from_lds();
-    }
-    if (n_orders > 0) {  // engine.go:101-109
-      eliminate(orders, n_orders);
-      update_stats();
-    }
-    if (first_err) {  // engine.go:111-113 -> turn_processor.go:55-57: production, stats, game-over skipped (H5)
-      aborted = true;
-      return first_err;
-    }
-    production(A.prod_general, A.prod_city, A.prod_normal, A.interval);  // :60
-    update_stats();                                                       // :65,170-179
-    check_game_over();
-    return 0u;
-  }
-
-  // ---- EngineInitializer.performInitialSetup (engine_initializer.go:218-225) -----------------
-  __device__ __forceinline__ void initial_setup() {
-    turn = 0;
-    chg = 0u;
-    vch = 0u;
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) vis[p] = 0u;
-    hflags &= ~HF_DONE;
-    update_stats();  // Turn == 0 => full
-    update_fog();    // Turn == 0 => full
-    check_game_over();
-  }
-
-  // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73) --------------------
-  // A player's packed mask is FOUR DIRECTION BIT-PLANES of fd dwords each: bit t of plane d = action
-  // (y*W+x)*4 + d of the reference, t = y*W + x.  Plane d is then just
-  //     (listed & owned & army > 1)  &  ("the neighbour in direction d is on the board, not a mountain")
-  // in the flat domain - two ANDs - and the row [d][i] is laid on lanes j = d*fd + i with one
-  // ds_bpermute per plane (lane j reads flat lane j mod fd), so that lane j stores dword j: one
-  // coalesced store per player.  out[p][k]: lane l holds dword l + 64k of player p's row.
-  // SERIALIZER = false: Engine.GetLegalActionMask, d = 0 up, 1 right, 2 down, 3 left (H10).
-  // SERIALIZER = true : Serializer.GenerateActionMask (internal/experience/serializer.go:112-176):
-  //   board owner (not the list), army >= 2, no Alive check, d = 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
-  // The player-independent half of the mask, laid out like a mask row: lane j (+64k) holds, for
-  // direction plane d = j / fd, the dword j % fd of "the d-neighbour is on the board and not a
-  // mountain".  Depends on the type planes and the geometry only: constant for the life of a board.
-  template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_targets(uint32_t (&okp)[MPASS], int fd) const {
-    const uint32_t notm = ~mtn & valid;  // in-board, not a mountain (Validate :58-64,:96-98)
-    const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);                  // target y-1 / y+1
-    const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;  // target x+1 / x-1
-    const uint32_t ok1 = SERIALIZER ? ok_dn : ok_rt, ok2 = SERIALIZER ? ok_lf : ok_dn, ok3 = SERIALIZER ? ok_rt : ok_lf;
-#pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      const int j = lane_id() + 64 * k;
-      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
-      const int addr = (j - d * fd) << 2;  // flat lane j mod fd
-      // cross-lane reads: all unconditional
-      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
-      const uint32_t g = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
-      okp[k] = (j < 4 * fd) ? g : 0u;
-    }
-  }
-  template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd, const uint32_t (&okp)[MPASS]) const {
-    uint32_t gt1 = 0u;  // army > 1 as a flat plane
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) scatter(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
-    uint32_t src[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1
-      const uint32_t m = SERIALIZER ? (own[p] & gt1) : (lst[p] & own[p] & gt1);
-      src[p] = (SERIALIZER || ((alive >> p) & 1u)) ? m : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      const int j = lane_id() + 64 * k;
-      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
-      const int addr = (j - d * fd) << 2;
-#pragma unroll
-      for (int p = 0; p < MAXP; ++p) out[p][k] = bperm(addr, src[p]) & okp[k];  // cross-lane: unconditional
-    }
-  }
-  template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
-    uint32_t okp[MPASS];
-    legal_targets<SERIALIZER>(okp, fd);
-    legal_masks<SERIALIZER>(out, fd, okp);
+    plane = (uint32_t)gvec_llvm_writelane((int)(uint32_t)ballot, 2 * s, (int)plane);
+    plane = (uint32_t)gvec_llvm_writelane((int)(uint32_t)(ballot >> 32), 2 * s + 1, (int)plane);
   }
 
   // ---- internal/experience/rewards.go helpers ---------------------------------------------------

@@ -9,90 +9,70 @@ namespace gvec {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
-// The per-turn step kernel and the query kernels hold a board of four or more players as PBoard (players
-// packed into register rows, gvec_packed.hpp): one-process A/B against Board, per turn: 20x20 4P +1 %,
-// 25x25 4P +8 %, 32x32 8P +15 % (no spills left), 15x15 2P -1.6 % (nothing to pack: stays on Board).
-// The fused rollout kernel stays on Board (same VALU count either way, 3 % faster unpacked).
-// -DGVEC_PACKED=0 builds everything on Board for A/B runs.
-#ifndef GVEC_PACKED
-#define GVEC_PACKED 1
-#endif
-constexpr bool packed_variant(int maxp) { return GVEC_PACKED != 0 && maxp >= 4; }
+// All turn logic runs on PBoard (players packed into register rows, gvec_packed.hpp); Board is the plain
+// layout of the conversion / experience kernels.
 template <int MAXP, int NSLOT>
-using HotBoard = std::conditional_t<packed_variant(MAXP), PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
+using Turn = PBoard<MAXP, NSLOT>;
 
 // =========================================================================================
-// random agent (DESIGN.md "Synthetic inputs"; mirrored by oracle agent_env)
+// random agent (DESIGN.md "Synthetic inputs"; mirrored by the oracle's agent_env)
 // =========================================================================================
-__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
-
-// index of the k-th (0-based) set bit of a wave-uniform word: lane i counts the set bits in
-// positions 0..i; the first lane whose count exceeds k names the bit
-__device__ __forceinline__ int select_kth(uint32_t word, uint32_t k) {
-  const uint32_t c = (uint32_t)__builtin_popcount(word & (0xFFFFFFFFu >> (31 - (lane_id() & 31))));
-  return (int)__builtin_ctz((uint32_t)__builtin_amdgcn_ballot_w64(c > k));
-}
-
-// All hashing / coordinate arithmetic runs on lanes (lane p = player p); only the choice of the
-// k-th legal move needs a wave-wide scan per player.  "k-th" counts the set bits of the player's packed
-// mask row in storage order: direction plane 0 tile 0.., then plane 1, ... (fd = dwords per plane).
-template <int MAXP, int NSLOT, typename BT>
-__device__ __forceinline__ void agent_sample(const BT& b,
-                                             const uint32_t (&lm)[MAXP][Board<MAXP, NSLOT>::MPASS], int fd, uint32_t ek,
+// Every alive player draws two hashes h1 = amix(key + turn*c1 + player*c2 + c3), h2 = amix(h1 ^ c4):
+//   no action            if (h1 & 0xFFFF) < agent_noop
+//   half move            if (h1 >> 16) < agent_half
+//   unchecked move       if invalid_permille > 0 and ((h2 & 0xFFFF) * 1000 >> 16) < invalid_permille:
+//                        tile ((h2 >> 16) * N) >> 16, direction (h1 >> 8) & 3  (H5 stress)
+//   else the kk-th legal move, kk = ((h2 >> 16) * count) >> 16, of Engine.GetLegalActionMask(player) in the
+//   order (t >> 5, d, t & 31): 32-tile blocks ascending, inside a block direction plane by direction plane
+//   (up, right, down, left), inside a plane tiles ascending.  No legal move: no action.
+// All players of a register are sampled at once: lane (row r, column c) counts the legal moves of player
+// r in tile block c, one row-wise prefix scan finds each row's lane, that lane finds its bit.
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void agent_sample(const Turn<MAXP, NSLOT>& b, const uint32_t (&m)[Turn<MAXP, NSLOT>::NR][4], uint32_t ek,
                                              const StepArgs& A, uint32_t& alo, uint32_t& ahi) {
-  const int invalid_permille = A.invalid_permille;
-  constexpr int MPASS = Board<MAXP, NSLOT>::MPASS;
+  using T = Turn<MAXP, NSLOT>;
+  constexpr int NR = T::NR, PPR = T::PPR, ROWL = T::ROWL;
   const int lane = lane_id();
-  const uint32_t h1 = fmix32(ek + (uint32_t)b.turn * 0x9E3779B1u + (uint32_t)lane * 0x7F4A7C15u + 0x165667B1u);
-  const uint32_t h2 = fmix32(h1 ^ 0x68E31DA4u);
-  const uint32_t h3 = fmix32(h2 + 0xB5297A4Du);
-  bool act = lane < b.P && ((b.alive >> lane) & 1u) && !((h1 & 0xFFFFu) < A.agent_noop);  // no-op (default p ~ 0.1)
-  const bool half = (h1 >> 16) < A.agent_half;                                        // default p ~ 0.3
-  const bool inv = invalid_permille > 0 && (int)mulhi32(h3, 1000u) < invalid_permille;
-  int t = (int)mulhi32(h2, (uint32_t)b.N);  // unchecked move (H5 stress) unless replaced below
-  int d = (int)(h3 & 3u);
-  const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64(act && !inv);
+  const uint32_t sbase = ek + (uint32_t)b.turn * 0x9E3779B1u + 0x165667B1u;  // wave-uniform
+  uint32_t mine = 0u;  // lane p: player p's draw, packed: t | d << 10 | act << 12 | half << 13
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
-    if (!((need >> p) & 1u)) continue;
-    uint32_t sc[MPASS];
-    uint32_t total = 0u;
-#pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      sc[k] = wave_scan_add((uint32_t)__builtin_popcount(lm[p][k])) + total;
-      total = rdlane(sc[k], 63);
-    }
-    if (total == 0u) {  // no legal move: no action
-      act = act && lane != p;
-      continue;
-    }
-    const uint32_t kk = mulhi32(rdlane(h2, p), total);
-    int jj = 0;
-    uint32_t word = 0u, below = 0u;
-    bool found = false;
-#pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(sc[k] > kk);
-      if (!found && m) {
-        const int j = __builtin_ctzll(m);
-        word = rdlane(lm[p][k], j);
-        below = rdlane(sc[k], j) - (uint32_t)__builtin_popcount(word);
-        jj = j + 64 * k;
-        found = true;
-      }
-    }
-    // row dword jj = direction plane jj / fd, tiles 32 * (jj % fd) ..
-    const int dd = (jj >= fd ? 1 : 0) + (jj >= 2 * fd ? 1 : 0) + (jj >= 3 * fd ? 1 : 0);
-    const int tt = 32 * (jj - dd * fd) + select_kth(word, kk - below);
-    t = (lane == p) ? tt : t;
-    d = (lane == p) ? dd : d;
+  for (int k = 0; k < NR; ++k) {
+    const uint32_t player = (uint32_t)T::lane_player(k);
+    const uint32_t h1 = amix(mad24(player, 0x4A7C15u, sbase));
+    const uint32_t h2 = amix(h1 ^ 0x68E31DA4u);
+    const uint32_t hi16 = h2 >> 16;
+    const bool act = b.lane_flag(b.alive, k) && !((h1 & 0xFFFFu) < A.agent_noop);  // alive implies player < P
+    const bool half = (h1 >> 16) < A.agent_half;
+    const bool inv = A.invalid_permille > 0 && (__umul24(h2 & 0xFFFFu, 1000u) >> 16) < (uint32_t)A.invalid_permille;
+    const uint32_t c0 = (uint32_t)__builtin_popcount(m[k][0]), c1 = c0 + (uint32_t)__builtin_popcount(m[k][1]);
+    const uint32_t c2 = c1 + (uint32_t)__builtin_popcount(m[k][2]), cnt = c2 + (uint32_t)__builtin_popcount(m[k][3]);
+    const uint32_t sc = row_scan_add<ROWL>(cnt);
+    const uint32_t total = row_last<ROWL>(sc);     // this row's number of legal moves (< 4096)
+    const uint32_t kk = __umul24(hi16, total) >> 16;
+    const uint32_t below = sc - cnt;
+    const bool sel = kk >= below && kk < sc;       // exactly one lane of a row with total > 0
+    const uint32_t r = kk - below;
+    const uint32_t d = (r >= c0 ? 1u : 0u) + (r >= c1 ? 1u : 0u) + (r >= c2 ? 1u : 0u);
+    const uint32_t base = (d == 0u) ? 0u : (d == 1u) ? c0 : (d == 2u) ? c1 : c2;
+    const uint32_t w = (d == 0u) ? m[k][0] : (d == 1u) ? m[k][1] : (d == 2u) ? m[k][2] : m[k][3];
+    const uint32_t t_sel = 32u * (uint32_t)T::col() + kth_set_bit(w, r - base);
+    const uint32_t pick = row_scan_or<ROWL>(sel ? (t_sel | (d << 10) | 0x8000u) : 0u);  // complete at the row's last lane
+    const uint32_t unchecked = (__umul24(hi16, (uint32_t)b.N) >> 16) | (((h1 >> 8) & 3u) << 10) | 0x8000u;
+    const uint32_t fin = inv ? unchecked : pick;
+    const bool go = act && (fin & 0x8000u) != 0u;
+    const uint32_t out = (fin & 0xFFFu) | (go ? 0x1000u : 0u) | (half ? 0x2000u : 0u);
+    // lane p <- the last lane of row p % PPR of register p / PPR
+    const uint32_t got = bperm((((lane % PPR) * ROWL) + ROWL - 1) << 2, out);
+    mine = (lane / PPR == k) ? got : mine;
   }
+  const bool act = lane < MAXP && (mine & 0x1000u) != 0u;
+  const int t = (int)(mine & 0x3FFu), d = (int)((mine >> 10) & 3u);
   const int y = (int)(__umul24((uint32_t)t, (uint32_t)b.recipW) >> 16), x = t - (int)__umul24((uint32_t)y, (uint32_t)b.W);  // t < 1024
   const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
   const uint32_t lo = ((uint32_t)x & 0xFFu) | (((uint32_t)y & 0xFFu) << 8) | (((uint32_t)(x + dx) & 0xFFu) << 16) |
                       (((uint32_t)(y + dy) & 0xFFu) << 24);
   alo = act ? lo : 0u;
-  ahi = act ? (GVEC_ACT_VALID | (half ? GVEC_ACT_HALF : 0u)) : 0u;
+  ahi = act ? (GVEC_ACT_VALID | ((mine & 0x2000u) ? GVEC_ACT_HALF : 0u)) : 0u;
 }
 
 // =========================================================================================
@@ -101,7 +81,6 @@ __device__ __forceinline__ void agent_sample(const BT& b,
 template <typename BT>
 __device__ __forceinline__ void load_board(BT& b, const uint32_t* hdr, const uint32_t* rows, const ArmyCRef& army, int fd) {
   b.load_hdr(hdr);
-  b.geometry();
   b.load_army(army);
   b.load_planes(rows, fd);
 }
@@ -112,7 +91,7 @@ __device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd
   const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
   const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
-  const int j = (int)mulhi32(hk, (uint32_t)A.pool_size);
+  const int j = (int)__umulhi(hk, (uint32_t)A.pool_size);
   load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, army_cref<NSLOT>(A.pool_army16, A.pool_army32, j), fd);
   b.hdr_set(H_EPISODE, episode);
   b.hdr_set(H_CNT_STEPS, cs);
@@ -120,44 +99,17 @@ __device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd
   b.hdr_set(H_CNT_DONE, cd);
 }
 
-template <int MAXP, int NSLOT>
-using Masks = uint32_t[MAXP][Board<MAXP, NSLOT>::MPASS];
-
-template <int MAXP, int NSLOT>
-__device__ __forceinline__ void load_masks(Masks<MAXP, NSLOT>& lm, const StepArgs& A, int env) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-    for (int q = 0; q < Board<MAXP, NSLOT>::MPASS; ++q) {
-      const int j = lane + 64 * q;
-      lm[p][q] = (j < A.mask_dw && p < A.pstride) ? A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] : 0u;
-    }
-}
-template <int MAXP, int NSLOT>
-__device__ __forceinline__ void store_masks(const Masks<MAXP, NSLOT>& lm, const StepArgs& A, int env) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-    for (int q = 0; q < Board<MAXP, NSLOT>::MPASS; ++q) {
-      const int j = lane + 64 * q;
-      if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
-    }
-}
-
 // ONE engine turn per launch, straight-line (gvec_step; per-turn rollouts).  AGENT: actions are
-// sampled on device from the legal-mask buffer, which the host guarantees to be current.
+// sampled on device from the legal-move planes of the resident state.
 // Waves per SIMD asked of the register allocator: the board state a variant holds (planes, army
-// slots, mask words) plus ~32 working registers.  <4,7> fits 64 registers = 8 waves/SIMD without a
+// slots, mask planes) plus ~32 working registers.  <4,7> fits 64 registers = 8 waves/SIMD without a
 // spill, which is worth 7 % over 7 waves (one-process A/B): the turn is a long dependent chain of
 // short cross-lane operations, and the VALU only stays fed with every wave slot occupied.
 constexpr int step_waves(int maxp, int nslot) {
   const int ppr = (nslot <= 7) ? 4 : 2;  // PBoard: players per plane register
-  const int plane_regs = packed_variant(maxp) ? 3 * ((maxp + ppr - 1) / ppr) + 5 : 3 * maxp + 5;
-  const int state = plane_regs + nslot + maxp * ((nslot > 8) ? 2 : 1);
-  // 8 waves only where they fit with room to spare: <2,16> at exactly 64 registers spills 40 bytes and runs
-  // 18 % slower than at 7 waves (171 vs 146 us per 65,536 32x32 boards)
+  const int nr = (maxp + ppr - 1) / ppr;
+  const int state = 3 * nr + 13 + nr + nslot + 4 * nr;  // packed planes, shared planes, rowbit, armies, mask planes
+  // 8 waves only where they fit with room to spare
   const int need = state + (state + 32 <= 62 ? 32 : 40);
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
@@ -171,8 +123,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
   constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];  // per wave: the action phase's army copy
-  using B = HotBoard<MAXP, NSLOT>;
-  constexpr int MPASS = B::MPASS;
+  using B = Turn<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
@@ -193,12 +144,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD);
   b.small = !(b.hflags & HF_WIDE);  // one turn from armies <= 65535: every sum of the turn stays below 2^23
   const bool emit = (A.flags & KF_EMIT) != 0u;
-  uint32_t lm[MAXP][MPASS], okp[MPASS];
+  uint32_t m[B::NR][4];
   uint32_t err = 0u;
-  bool types_dirty = false, changed = true, okp_valid = false;
+  bool types_dirty = false, changed = true;
   const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
   if (can_redeal && ((b.hflags & HF_DONE) || force_redeal)) {
-    redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
+    redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);  // the pool board brings its own gt1 plane
     types_dirty = true;
   } else if (b.hflags & HF_DONE) {
     err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
@@ -206,13 +157,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   } else {
     uint32_t alo = 0u, ahi = 0u;
     if constexpr (AGENT) {
-      // The agent's input is recomputed from the board instead of read back from the mask buffer the
-      // previous launch wrote: the kernel sits on its HBM floor (scripts/microbench/copy_pattern.hip)
-      // with VALU time to spare, so ~75 vector instructions are cheaper than 832 bytes per env.
-      b.template legal_targets<false>(okp, FD);
-      okp_valid = true;
-      b.template legal_masks<false>(lm, FD, okp);
-      agent_sample<MAXP, NSLOT>(b, lm, FD, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
+      // the agent's input: the legal-move planes of the resident state, rebuilt from the stored gt1 plane
+      // (7 vector instructions; re-reading the 832-byte masks the previous launch wrote would cost more)
+      b.template legal_planes<false>(m);
+      agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
       if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
     } else if (lane < A.pstride) {
       const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
@@ -221,6 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     }
     bool aborted;
     err = b.turn_step(alo, ahi, A, aborted);
+    b.refresh_gt1();
     b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
@@ -230,24 +179,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (emit && (changed || !(A.flags & KF_LMVALID))) {
-    if (!okp_valid) b.template legal_targets<false>(okp, FD);  // re-dealt board, or actions came from the host
-    b.template legal_masks<false>(lm, FD, okp);
-    store_masks<MAXP, NSLOT>(lm, A, env);
+    b.template legal_planes<false>(m);
+    b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, FD, A.pstride);
   }
 }
 
 // Waves per SIMD to ask of the register allocator for the fused rollout kernel.  With no HBM traffic
 // inside the turn loop the kernel is latency / issue bound, and occupancy pays even at the price of
-// a few scratch spills (measured on <4,7>, one-process A/B: default 4 waves 851 M env-steps/s,
-// 5: 934 M, 6: 1,024 M, 7: 1,056 M, 8: 990-1,050 M depending on where the spills land).  The bound
-// scales with the board state the variant must hold: planes + army slots + mask words + ~40
-// working registers.
+// a few scratch spills; a spill inside the turn loop of the big variants costs far more than a wave.
 constexpr int rollout_waves(int maxp, int nslot) {
-  // (the 8-player variants run on PBoard and need fewer plane registers, but asking for more waves there
-  // only brings the spills back: measured 32x32 8P, 101 us/turn with this bound, 160 us with a tighter one)
-  // Boards above 448 tiles carry two mask words per player and longer slot loops: a spill inside the turn
-  // loop costs far more than a wave (measured <4,10>, 25x25 4P: 91 us/turn at 5 waves, 135 at 6, 150 at 7).
-  const int need = (3 * maxp + 5) + nslot + maxp * ((nslot > 8) ? 2 : 1) + (nslot >= 10 ? 60 : 40);
+  const int ppr = (nslot <= 7) ? 4 : 2;
+  const int nr = (maxp + ppr - 1) / ppr;
+  const int need = 3 * nr + 13 + nr + nslot + 4 * nr + (nslot >= 10 ? 60 : 44);
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
   return w > 8 ? 8 : (w < 2 ? 2 : w);
@@ -258,11 +201,7 @@ constexpr int rollout_waves(int maxp, int nslot) {
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
-  // measured (one-process A/B of the fused loop): 20x20 4P 3 % faster on the unpacked registers (same VALU
-  // count, shorter chains), 32x32 8P 11 % faster packed (29 plane registers become 11); boards above 448 tiles
-  // run packed as well (fewer registers to spill)
-  using B = std::conditional_t<packed_variant(MAXP) && (MAXP >= 8 || NSLOT >= 10), PBoard<MAXP, NSLOT>, Board<MAXP, NSLOT>>;
-  constexpr int MPASS = B::MPASS;
+  using B = Turn<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
@@ -270,27 +209,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.larmy = army_shadow[wave];
   const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd);
-  uint32_t lm[MAXP][MPASS];
+  uint32_t m[B::NR][4];
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
   const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
   int k = 0;
   // The hot inner loop plays turns while the game is live; the rare events (game over: re-deal from
   // the pool, or freeze) sit in the outer loop so they do not shape the inner loop's registers.
-  uint32_t okp[MPASS];
   for (;;) {
-    b.template legal_targets<false>(okp, A.fd);  // once per board: the type planes only change on a re-deal
-    b.template legal_masks<false>(lm, A.fd, okp);  // the masks of the CURRENT state: the agent's input, the output at the end
+    b.template legal_planes<false>(m);  // the planes of the CURRENT state: the agent's input, the output at the end
     while (k < A.turns && !(b.hflags & HF_DONE)) {
       uint32_t alo, ahi;
-      agent_sample<MAXP, NSLOT>(b, lm, A.fd, ek, A, alo, ahi);
+      agent_sample<MAXP, NSLOT>(b, m, ek, A, alo, ahi);
       bool aborted;
       err = b.turn_step(alo, ahi, A, aborted);
       n_steps += 1u;
       n_abort += aborted ? 1u : 0u;
       n_done += (b.hflags & HF_DONE) ? 1u : 0u;
       ++k;
-      b.template legal_masks<false>(lm, A.fd, okp);
+      b.refresh_gt1();
+      b.template legal_planes<false>(m);
     }
     if (k >= A.turns) break;
     if (!can_redeal) {
@@ -308,37 +246,50 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
-  store_masks<MAXP, NSLOT>(lm, A, env);
+  b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
 }
 
 // legal masks / agent actions of the resident state (no turn is played)
 // MODE 0: Engine.GetLegalActionMask   1: random-agent actions   2: Serializer.GenerateActionMask
 template <int MAXP, int NSLOT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A) {
-  using B = HotBoard<MAXP, NSLOT>;
-  constexpr int MPASS = B::MPASS;
+  using B = Turn<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
-  uint32_t lm[MAXP][MPASS];
-  if constexpr (MODE == 2) b.template legal_masks<true>(lm, A.fd);
-  else b.template legal_masks<false>(lm, A.fd);
+  uint32_t m[B::NR][4];
+  if constexpr (MODE == 2) b.template legal_planes<true>(m);
+  else b.template legal_planes<false>(m);
   if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
-    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, lm, A.fd, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
+    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
   } else {
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p)
-#pragma unroll
-      for (int q = 0; q < MPASS; ++q) {
-        const int j = lane + 64 * q;
-        if (j < A.mask_dw && p < A.pstride) A.legal[((size_t)env * A.pstride + p) * A.mask_dw + j] = lm[p][q];
-      }
+    b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
   }
+}
+
+// EngineInitializer.performInitialSetup (engine_initializer.go:218-225) for the envs an import marked
+// (HF_SETUP): full stats pass, full fog pass, game-over check on the freshly imported board.
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void setup_kernel(ImportArgs A) {
+  using B = Turn<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6);
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.n) return;
+  const int env = A.env_ids ? uni(A.env_ids[i]) : A.dst_begin + i;
+  if (env < 0 || env >= A.dst_envs) return;  // reported by the import kernel
+  B b;
+  b.larmy = nullptr;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  if (!(b.hflags & HF_SETUP)) return;  // this env's input was rejected: left as it was
+  b.hflags &= ~HF_SETUP;
+  b.initial_setup();
+  b.store_hdr(A.hdr + (size_t)env * HDR_DW, 0u);
+  b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, false);
 }
 
 // =========================================================================================
@@ -351,7 +302,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(Experien
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
-  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   uint32_t tail = 0u;  // lane p: territory, lane MAXP+p: armies, lane 2*MAXP: turn, +1: W|H<<8
@@ -377,7 +327,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(Experienc
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
-  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[MAXP * A.fd + lane] : 0u;
@@ -434,7 +383,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
-  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const bool fog_on = (b.hflags & HF_FOG) != 0u;
   uint32_t own_any = 0u;
@@ -498,7 +446,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
 
   B b;
-  b.larmy = nullptr;
   if (A.fresh) {
     b.W = A.s_width[i];
     b.H = A.s_height[i];
@@ -519,10 +466,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     b.chg = b.vch = b.gen = b.city = b.mtn = 0u;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) b.army[s] = 0;
-    b.geometry();
   } else {
     load_board(b, hdr, rows, army, A.fd);
   }
+  b.geometry();
 
   // per-tile source planes are read coalesced in the tile domain (lane l, slot s = tile 64s+l);
   // each predicate becomes a flat plane through the wave ballot
@@ -610,7 +557,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
     if (A.s_army_count) b.hdr_set(H_ARMYCNT + p, (uint32_t)A.s_army_count[po + p]);
     if (A.s_general_idx) b.hdr_set(H_GIDX + p, (uint32_t)A.s_general_idx[po + p]);
   }
-  if (A.init) b.initial_setup();
+  // the planes that are functions of the board: rebuilt on every import (the type planes may have changed)
+  b.targets();
+  b.refresh_gt1();
+  if (A.init) b.hflags |= HF_SETUP;  // performInitialSetup runs in setup_kernel, on the turn engine's layout
   b.store_army(army);
   b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_planes(rows, A.fd, A.row_dw, true);
@@ -627,7 +577,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void export_kernel(ExportArgs
   if (i >= A.n) return;
   const int env = A.env_begin + i;
   B b;
-  b.larmy = nullptr;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
   const size_t to = (size_t)i * A.stride, po = (size_t)i * A.max_p;
   const uint32_t special = b.gen | b.city | b.mtn;
@@ -708,7 +657,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
   uint32_t* rec_rows = A.rec_rows + (size_t)i * A.row_dw;
   int32_t* rec_army = A.rec_army + (size_t)i * NSLOT * 64;
   B b;
-  b.larmy = nullptr;
   if constexpr (!IMPORT) {
     load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
     b.hflags &= ~HF_WIDE;
@@ -724,9 +672,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
       return;
     }
     b.hflags &= (HF_DONE | HF_FOG);
-    b.geometry();
     army_load_wide<NSLOT>(b.army, rec_army);
     b.load_planes(rec_rows, A.fd);
+    b.geometry();  // the constant planes are rebuilt, never taken from the slab
     // nothing outside the board may be set: the turn logic relies on it
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
@@ -742,6 +690,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
     b.mtn &= b.valid;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) b.army[s] = (64 * s + lane < b.N) ? b.army[s] : 0;
+    b.targets();
+    b.refresh_gt1();
     b.store_army(army_ref<NSLOT>(A.army16, A.army32, env));
     b.store_hdr(A.hdr + (size_t)env * HDR_DW, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);
     b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
@@ -908,11 +858,27 @@ __global__ void selftest_kernel(int32_t* out) {
   if (wave_scan_add(v) != expect) fail = fail ? fail : 3;
   if (wave_sum(v) != (uint32_t)(63 * 64 / 2 * 3 + 64)) fail = fail ? fail : 4;
   if (bperm(4 * ((lane * 7) & 63), v) != (uint32_t)(((lane * 7) & 63) * 3 + 1)) fail = fail ? fail : 5;
-  {  // select_kth is a wave-wide operation on uniform inputs
-    const bool bad = select_kth(0x80000105u, 0) != 0 || select_kth(0x80000105u, 1) != 2 || select_kth(0x80000105u, 2) != 8 ||
-                     select_kth(0x80000105u, 3) != 31;
-    fail = (!fail && bad) ? 7 : fail;
+  {  // per-lane k-th set bit: lane l asks for bit number l % popcount
+    const uint32_t w = 0x80000105u ^ ((uint32_t)lane * 0x9E3779B1u);
+    const uint32_t r = (uint32_t)lane % (uint32_t)__builtin_popcount(w);
+    uint32_t want = 0u, seen = 0u;
+    for (uint32_t i = 0; i < 32u; ++i)
+      if ((w >> i) & 1u) {
+        if (seen == r) want = i;
+        ++seen;
+      }
+    if (kth_set_bit(w, r) != want) fail = fail ? fail : 7;
   }
+  {  // row-wise scans and the row-last broadcast, 16- and 32-lane rows
+    uint32_t e16 = 0u, e32 = 0u, o16 = 0u, o32 = 0u;
+    for (int l = lane & ~15; l <= lane; ++l) e16 += (uint32_t)(l * 3 + 1), o16 |= 1u << (l & 31);
+    for (int l = lane & ~31; l <= lane; ++l) e32 += (uint32_t)(l * 3 + 1), o32 |= 1u << (l & 31);
+    if (row_scan_add<16>(v) != e16 || row_scan_add<32>(v) != e32) fail = fail ? fail : 8;
+    if (row_scan_or<16>(1u << (lane & 31)) != o16 || row_scan_or<32>(1u << (lane & 31)) != o32) fail = fail ? fail : 9;
+    if (row_last<16>(v) != (uint32_t)((lane | 15) * 3 + 1) || row_last<32>(v) != (uint32_t)((lane | 31) * 3 + 1)) fail = fail ? fail : 10;
+  }
+  if ((uint32_t)gvec_llvm_writelane(777, 5, (int)v) != (lane == 5 ? 777u : v)) fail = fail ? fail : 11;
+  if (mad24(v, 3u, 5u) != v * 3u + 5u) fail = fail ? fail : 12;
   const unsigned long long any = __builtin_amdgcn_ballot_w64(fail != 0);
   if (lane == 0) out[0] = any ? (int32_t)(__builtin_ctzll(any) * 16 + rdlane((uint32_t)fail, (int)__builtin_ctzll(any))) : 0;
 }
@@ -1018,6 +984,13 @@ hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((import_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
+                       0, s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_setup(const Variant& v, const ImportArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((setup_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.n), dim3(64 * WAVES_PER_BLOCK),
                        0, s, a);
     return hipGetLastError();
   });

@@ -127,6 +127,8 @@ hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_
 hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_import(const Variant& v, const ImportArgs& a, hipStream_t s);
+// performInitialSetup for the envs the import of the same ImportArgs marked (a.init)
+hipError_t launch_setup(const Variant& v, const ImportArgs& a, hipStream_t s);
 hipError_t launch_export(const Variant& v, const ExportArgs& a, hipStream_t s);
 hipError_t launch_records(const Variant& v, const RecordArgs& a, bool import, hipStream_t s);
 hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s);

@@ -1,45 +1,98 @@
-// gvec_packed.hpp — the hot kernels' register layout: per-player planes packed into register ROWS.
+// gvec_packed.hpp — the turn engine's register layout: per-player planes packed into register ROWS.
 //
-// Board (gvec_device.hpp) keeps one register per (plane kind, player): 12 registers of which a 20x20
-// board uses 13 of 64 lanes each.  PBoard lays the players of one kind side by side in one register:
+// Board (gvec_device.hpp) keeps one register per (plane kind, player), of which a 20x20 board uses 13 of
+// 64 lanes.  PBoard lays the players of one kind side by side in one register:
 //
 //     row r of register k (lanes r*ROWL .. r*ROWL + ROWL-1)  =  player k*PPR + r
 //     lane column c = lane % ROWL                            =  dword c of the bit string (tiles 32c..32c+31)
 //
 // with ROWL = 16 (PPR = 4 players per register) for boards up to 448 tiles and ROWL = 32 (PPR = 2) above.
-// The planes every player shares (chg, vch, gen, city, mtn) and the geometry masks are REPLICATED in
-// every row, so a packed plane combines with them lane by lane.  Every per-player flat operation of the
-// turn (fog dilations, list refresh, mask sources) now runs once per register instead of once per
-// player.  The wave-wide bit-string shifts stay correct because the last lanes of every row hold no
-// tiles (fd <= 14 of 16, fd <= 32 of 32 - the one full case is masked explicitly).
+// The planes every player shares (chg, vch, gt1, the type planes, the geometry masks and the four
+// "target is free" planes) are REPLICATED in every row, so a packed plane combines with them lane by lane.
+// Every per-player flat operation of the turn (fog dilations, list refresh, the legal-move planes, the
+// random agent's prefix scan) runs once per register instead of once per player.  The wave-wide bit-string
+// shifts stay correct because the last lanes of every row hold no tiles (fd <= 14 of 16, fd <= 32 of 32 -
+// the one full case is masked explicitly).
 //
-// HBM layout, tile domain (armies), header and the semantics are exactly Board's; the cold kernels
-// (import / export / experience) keep using Board.  Every routine cites the Go function it reproduces,
-// like its counterpart in gvec_device.hpp.
+// All turn logic lives here (TurnProcessor.ProcessTurn and everything below it, the legal-action mask,
+// performInitialSetup); every routine cites the Go function it reproduces, paths relative to
+// /root/reference/internal/game/.  HBM layout, tile domain (armies) and header are Board's.
 #pragma once
 #include "gvec_device.hpp"
 
 namespace gvec {
 
+// ---- row-wise cross-lane helpers (a "row" = ROWL consecutive lanes) ---------------------------------
+template <int ROWL>
+__device__ __forceinline__ uint32_t row_scan_add(uint32_t v) {  // inclusive prefix sum inside every row
+  v += dpp0<0x111>(v);  // row_shr:1 (DPP rows are 16 lanes: zeros are shifted in at their start)
+  v += dpp0<0x112>(v);
+  v += dpp0<0x114>(v);
+  v += dpp0<0x118>(v);
+  if constexpr (ROWL == 32) v += dpp0<0x142, 0xa>(v);  // row_bcast15 into DPP rows 1 and 3
+  return v;
+}
+template <int ROWL>
+__device__ __forceinline__ uint32_t row_scan_or(uint32_t v) {  // inclusive prefix OR inside every row
+  v |= dpp0<0x111>(v);
+  v |= dpp0<0x112>(v);
+  v |= dpp0<0x114>(v);
+  v |= dpp0<0x118>(v);
+  if constexpr (ROWL == 32) v |= dpp0<0x142, 0xa>(v);
+  return v;
+}
+// every lane receives the value of its row's LAST lane (ds_swizzle bit mode: lane = (lane & and) | or)
+template <int ROWL>
+__device__ __forceinline__ uint32_t row_last(uint32_t v) {
+  if constexpr (ROWL == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F << 5);
+}
+
+// position of the r-th (0-based) set bit of w, per lane (r < popcount(w), else unspecified)
+__device__ __forceinline__ uint32_t kth_set_bit(uint32_t w, uint32_t r) {
+  uint32_t pos = 0u;
+#pragma unroll
+  for (int width = 16; width >= 1; width >>= 1) {
+    const uint32_t c = (uint32_t)__builtin_popcount(__builtin_amdgcn_ubfe(w, pos, (uint32_t)width));
+    const bool ge = r >= c;
+    r = ge ? r - c : r;
+    pos = ge ? pos + (uint32_t)width : pos;
+  }
+  return pos;
+}
+
+// ---- the random agent's mixer (DESIGN.md "Synthetic inputs"; mirrored by the oracle's ora_amix) --------
+// Two rounds of xorshift + 24-bit multiply: v_mul_u32_u24 is full rate, fmix32's v_mul_lo_u32 costs four
+// issue slots each (the step kernel is VALU-issue bound: three fmix32 per env-step were 5 % of it).
+__device__ __forceinline__ uint32_t amix(uint32_t x) {
+  x ^= x >> 15;
+  x = __umul24(x, 0xE8A54Du);
+  x ^= x >> 13;
+  x = __umul24(x, 0xAA34A7u);
+  x ^= x >> 15;
+  return x;
+}
+
 template <int MAXP, int NSLOT>
 struct PBoard {
   using PL = Planes<MAXP>;
-  static constexpr int MPASS = (NSLOT > 8) ? 2 : 1;
   static constexpr int PPR = (NSLOT <= 7) ? 4 : 2;    // players per plane register
   static constexpr int ROWL = 64 / PPR;               // lanes per row
   static constexpr int NR = (MAXP + PPR - 1) / PPR;   // registers per plane kind
   static constexpr bool FULL_ROWS = (2 * NSLOT >= ROWL);  // a plane can fill its row: shifts must not cross rows
 
   uint32_t own[NR], lst[NR], vis[NR];         // packed: row r of register k = player k*PPR + r
-  uint32_t chg, vch, gen, city, mtn;          // replicated in every row
-  uint32_t valid, ncol0, ncolL;               // replicated geometry masks (see Board)
-  uint32_t rowbit[NR];                        // 1 << (the player this lane holds in register k): set by geometry()
+  uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
+  uint32_t valid, ncol0, ncolL, ok[4];        // replicated constant planes (see Board)
+  uint32_t rowbit[NR];                        // 1 << (the player this lane holds in register k)
   int32_t army[NSLOT];                        // tile domain, as in Board
   uint32_t hv;
-  int32_t* larmy;
+  int32_t* larmy;                             // LDS shadow of the armies during the action phase: tile t at larmy[t]
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
-  bool small = false;  // see Board::small
+  // every army stays below 2^23 until the board is stored (true for one turn from a NARROW load): the
+  // masked sums may then use full-rate 24-bit multiply-adds.  Set by the kernel, never by load_*.
+  bool small = false;
 
   static __device__ __forceinline__ int col() { return lane_id() & (ROWL - 1); }
   static __device__ __forceinline__ int row() { return lane_id() / ROWL; }
@@ -48,21 +101,6 @@ struct PBoard {
   // bit (k*PPR + row) of a per-player bit set: "the property holds for this lane's player"
   __device__ __forceinline__ bool lane_flag(uint32_t bits, int k) const { return (bits & rowbit[k]) != 0u; }
   static __device__ __forceinline__ bool in_row_of(int p) { return row() == (p % PPR); }
-
-  // ---- geometry (Board::geometry with the lane's column) ---------------------------------------
-  __device__ __forceinline__ void geometry() {
-#pragma unroll
-    for (int k = 0; k < NR; ++k) rowbit[k] = 1u << lane_player(k);
-    const int t0 = 32 * col();
-    const int left = N - t0;
-    valid = (left <= 0) ? 0u : (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
-    const uint32_t pat = kColumnPattern[W];
-    const int q = (int)(__umul24((uint32_t)t0, (uint32_t)recipW) >> 16);
-    const int x0 = t0 - (int)__umul24((uint32_t)q, (uint32_t)W);
-    const uint32_t col0 = pat << (x0 ? W - x0 : 0);
-    ncol0 = ~col0;
-    ncolL = ~__builtin_amdgcn_alignbit(next_lane(col0), col0, 1);
-  }
 
   // ---- bit-string shifts inside a row -------------------------------------------------------------
   static __device__ __forceinline__ uint32_t prev_lane(uint32_t m) {
@@ -83,6 +121,7 @@ struct PBoard {
   __device__ __forceinline__ uint32_t dnW(uint32_t m) const { return (uint32_t)((((uint64_t)next_lane(m) << 32) | (uint64_t)m) >> W); }
   __device__ __forceinline__ uint32_t dil_h(uint32_t m) const { return m | (up1(m) & ncol0) | (dn1(m) & ncolL); }
   __device__ __forceinline__ uint32_t dil_v(uint32_t m) const { return (m | upW(m) | dnW(m)) & valid; }
+  // 3x3 / 5x5 neighbourhoods (visibility_optimized.go:9-13, :104-105)
   __device__ __forceinline__ uint32_t dil3(uint32_t m) const { return dil_v(dil_h(m)); }
 
   // OR of the rows of a packed plane, replicated into every row
@@ -90,16 +129,6 @@ struct PBoard {
     if constexpr (PPR == 4) x |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);  // lane ^ 16
     x |= bperm((lane_id() ^ 32) << 2, x);
     return x;
-  }
-  // player p's plane out of its packed register, replicated into every row (cross-lane: uniform flow only)
-  __device__ __forceinline__ uint32_t unpack(const uint32_t (&reg)[NR], int p) const {
-    uint32_t r = 0u;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const uint32_t g = bperm((((p % PPR) * ROWL) + col()) << 2, reg[k]);
-      r = (k == p / PPR) ? g : r;
-    }
-    return r;
   }
 
   // ---- header (Board's) ---------------------------------------------------------------------------
@@ -115,6 +144,8 @@ struct PBoard {
     N = W * H;
     alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rowbit[k] = 1u << lane_player(k);
   }
   __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
@@ -139,13 +170,23 @@ struct PBoard {
       lst[k] = on ? b : 0u;
       vis[k] = on ? c : 0u;
     }
-    const uint32_t a = gs[PL::CHG * fd], b = gs[PL::VCH * fd], c = gs[PL::GEN * fd], d = gs[PL::CITY * fd], e = gs[PL::MTN * fd];
-    chg = in ? a : 0u;
-    vch = in ? b : 0u;
-    gen = in ? c : 0u;
-    city = in ? d : 0u;
-    mtn = in ? e : 0u;
+    auto ld = [&](int plane) {
+      const uint32_t v = gs[plane * fd];
+      return in ? v : 0u;
+    };
+    chg = ld(PL::CHG);
+    vch = ld(PL::VCH);
+    gt1 = ld(PL::GT1);
+    gen = ld(PL::GEN);
+    city = ld(PL::CITY);
+    mtn = ld(PL::MTN);
+    valid = ld(PL::VALID);
+    ncol0 = ld(PL::NCOL0);
+    ncolL = ld(PL::NCOLL);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ok[d] = ld(PL::OK + d);
   }
+  // The planes from GEN on change only when the env is re-dealt (with_types).
   __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
     const bool in = col() < fd;
     uint32_t* gp = rows_env + row() * fd + col();
@@ -159,14 +200,22 @@ struct PBoard {
     }
     const int lane = lane_id();
     if (lane < fd) {  // lanes 0..fd-1 are row 0, columns 0..fd-1 (fd <= ROWL)
-      rows_env[PL::CHG * fd + lane] = chg;
-      rows_env[PL::VCH * fd + lane] = vch;
+      uint32_t* g = rows_env + lane;
+      g[PL::CHG * fd] = chg;
+      g[PL::VCH * fd] = vch;
+      g[PL::GT1 * fd] = gt1;
       if (with_types) {
-        rows_env[PL::GEN * fd + lane] = gen;
-        rows_env[PL::CITY * fd + lane] = city;
+        g[PL::GEN * fd] = gen;
+        g[PL::CITY * fd] = city;
+        g[PL::MTN * fd] = mtn;
+        g[PL::VALID * fd] = valid;
+        g[PL::NCOL0 * fd] = ncol0;
+        g[PL::NCOLL * fd] = ncolL;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[(PL::OK + d) * fd] = ok[d];
       }
     }
-    if (with_types && lane < row_dw - PL::MTN * fd) rows_env[PL::MTN * fd + lane] = (lane < fd) ? mtn : 0u;  // + the block's padding
+    if (with_types && lane < row_dw - (PL::OK + 3) * fd) rows_env[(PL::OK + 3) * fd + lane] = (lane < fd) ? ok[3] : 0u;  // + the block's padding
   }
   // narrow (u16 pairs) / wide (int32 escape) army storage: see gvec_device.hpp "army storage"
   __device__ __forceinline__ void load_army(const ArmyCRef& a) {
@@ -183,7 +232,9 @@ struct PBoard {
     }
   }
 
-  // ---- LDS army shadow of the action phase (Board's) -----------------------------------------------
+  // ---- LDS army shadow of the action phase ---------------------------------------------------------
+  // During the action phase the armies live in an LDS shadow: a wave-uniform tile index is one
+  // broadcast ds_read / one single-lane ds_write instead of an NSLOT-way register select chain.
   __device__ __forceinline__ void army_to_lds() {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) larmy[64 * s + lane_id()] = army[s];
@@ -223,17 +274,22 @@ struct PBoard {
     const int lane = lane_id();
     return __builtin_amdgcn_ubfe(bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
-  // tile predicates -> flat plane: row 0 first (lane == constant: the selects take scalar masks, no vector
-  // compares), then one ds_bpermute copies row 0 into every row
-  __device__ __forceinline__ void scatter_row0(uint32_t& plane, unsigned long long ballot, int s) const {
-    const int lane = lane_id();
-    plane = (lane == 2 * s) ? (uint32_t)ballot : plane;
-    plane = (lane == 2 * s + 1) ? (uint32_t)(ballot >> 32) : plane;
-  }
   static __device__ __forceinline__ uint32_t replicate_row0(uint32_t plane) { return bperm(col() << 2, plane); }
   // popcount of a replicated plane (row 0 only)
   __device__ __forceinline__ int count_shared(uint32_t plane) const {
     return (int)wave_sum((lane_id() < ROWL) ? (uint32_t)__builtin_popcount(plane) : 0u);
+  }
+  // Tile.Army > 1 as a replicated flat plane: the ballot of slot s is dwords 2s, 2s+1 of the bit string
+  // (written into row 0 with v_writelane: 2*NSLOT <= ROWL), one ds_bpermute copies row 0 into every row
+  __device__ __forceinline__ void refresh_gt1() {
+    uint32_t g = 0u;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(army[s] > 1);
+      g = (uint32_t)gvec_llvm_writelane((int)(uint32_t)b, 2 * s, (int)g);
+      g = (uint32_t)gvec_llvm_writelane((int)(uint32_t)(b >> 32), 2 * s + 1, (int)g);
+    }
+    gt1 = replicate_row0(g);
   }
 
   // ---- Engine.updateFogOfWarOptimized (visibility_optimized.go:16-97) ---------------------------------
@@ -248,7 +304,7 @@ struct PBoard {
       }
       return;
     }
-    if (nv == 0) return;
+    if (nv == 0) return;  // incremental update over an empty set is the identity
     // :56-97 affected = board owners within 5x5 of V (:100-116); clear all players in 3x3 of V
     // (:132-150); re-light affected, alive players from their lists (:85-94)
     const uint32_t near3 = dil3(vch), near5 = dil3(near3), clr = ~near3;
@@ -267,7 +323,12 @@ struct PBoard {
     }
   }
 
-  // ---- one reduction tree for MAXP accumulators (Board::multi_sum) ---------------------------------
+  // Wave-wide sums of MAXP per-lane accumulators in ONE reduction tree (a tree per player costs 6 DPP
+  // adds each).  First the accumulators are folded into one register, lane l keeping class
+  // l & (MAXP-1): at each level a lane keeps its own class's half and hands the other half to its
+  // partner (quad_perm / row_ror swaps).  Then lanes of equal class are summed: row_shr inside a row of
+  // 16, ds_swizzle (xor 16) and ds_bpermute (xor 32) across rows.  Returns a register whose lanes
+  // H_ARMYCNT+p hold the total of acc[p].
   __device__ __forceinline__ uint32_t multi_sum(const int32_t (&acc)[MAXP]) const {
     static_assert(MAXP == 2 || MAXP == 4 || MAXP == 8, "fold levels are written for 2, 4 or 8 players");
     static_assert(H_ARMYCNT == 4, "the final row_shl assumes header lanes 4..4+MAXP-1");
@@ -280,7 +341,7 @@ struct PBoard {
 #pragma unroll
       for (int i = 0; i < MAXP / 2; ++i) {
         const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
-        m[i] = keep + dpp0<0xB1>(give);
+        m[i] = keep + dpp0<0xB1>(give);  // quad_perm [1,0,3,2]
       }
     }
     if constexpr (MAXP >= 4) {
@@ -288,21 +349,21 @@ struct PBoard {
 #pragma unroll
       for (int i = 0; i < MAXP / 4; ++i) {
         const uint32_t keep = hi ? m[2 * i + 1] : m[2 * i], give = hi ? m[2 * i] : m[2 * i + 1];
-        m[i] = keep + dpp0<0x4E>(give);
+        m[i] = keep + dpp0<0x4E>(give);  // quad_perm [2,3,0,1]
       }
     }
     if constexpr (MAXP >= 8) {
       const bool hi = (lane & 4) != 0;
       const uint32_t keep = hi ? m[1] : m[0], give = hi ? m[0] : m[1];
-      m[0] = keep + dpp0<0x124>(give);
+      m[0] = keep + dpp0<0x124>(give);  // row_ror:4 (the partner differs in bit 2; a bijection is all a sum needs)
     }
     uint32_t r = m[0];
-    if constexpr (MAXP <= 2) r += dpp0<0x112>(r);
-    if constexpr (MAXP <= 4) r += dpp0<0x114>(r);
-    r += dpp0<0x118>(r);
-    r += (uint32_t)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);
+    if constexpr (MAXP <= 2) r += dpp0<0x112>(r);  // row_shr:2
+    if constexpr (MAXP <= 4) r += dpp0<0x114>(r);  // row_shr:4
+    r += dpp0<0x118>(r);                           // row_shr:8 -> the last MAXP lanes of each row hold the row's sums
+    r += (uint32_t)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);  // lane ^ 16
     r += bperm((lane ^ 32) << 2, r);
-    return dpp0<0x100 + 12 - MAXP>(r);
+    return dpp0<0x100 + 12 - MAXP>(r);  // row_shl: lanes 16-MAXP.. of row 0 -> lanes 4..
   }
 
   // ---- Engine.updatePlayerStats (stats.go:8-144) ------------------------------------------------------
@@ -329,7 +390,7 @@ struct PBoard {
         for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
       }
     }
-    {
+    {  // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
       const int lane = lane_id();
       const uint32_t tot = multi_sum(acc);
       hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
@@ -343,7 +404,8 @@ struct PBoard {
       for (int r = 0; r < PPR; ++r) {
         const int p = k * PPR + r;
         if (p < MAXP) {
-          // GeneralIdx: the highest listed general tile (see Board::update_stats)
+          // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two or more
+          // generals that order depends on Go map iteration.  Here: the highest listed general tile.
           const unsigned long long rowbits = (ROWL == 32) ? 0xFFFFFFFFull : 0xFFFFull;
           const uint32_t dw = (uint32_t)((nz >> (r * ROWL)) & rowbits);
           int gi = -1;
@@ -371,10 +433,10 @@ struct PBoard {
     const uint32_t mn = (grow && pn > 0) ? (listed_alive & normal) : 0u;
     chg |= mg | mc | mn;  // :59-61 (prod > 0 only)
     const int an = (grow && pn > 0) ? pn : pc;
-    if (pg == pc && pc == an) {
+    if (pg == pc && pc == an) {  // one rate for every producing tile: one gather per slot
       const uint32_t m = mg | mc | mn;
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)(__umul24(gather(m, s), (uint32_t)pg) + (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
+      for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)mad24(gather(m, s), (uint32_t)pg, (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
     } else {
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) army[s] += (pg & gather_mask(mg, s)) + (pc & gather_mask(mc, s)) + (pn & gather_mask(mn, s));
@@ -384,11 +446,15 @@ struct PBoard {
   // ---- WinConditionChecker.CheckGameOver (rules/win_conditions.go:21-57) ---------------------------
   __device__ __forceinline__ void check_game_over() {
     const int na = __builtin_popcount(alive);
-    const bool over = (P > 1) ? (na <= 1) : (na == 0);
+    const bool over = (P > 1) ? (na <= 1) : (na == 0);  // originalPlayers == len(Players)
     hflags = over ? (hflags | HF_DONE) : (hflags & ~HF_DONE);
+    // the winner is re-derived from Alive on read-back, like Engine.GetWinner (engine.go:248-263)
   }
 
-  // ---- the action phase (Board's, on packed ownership) -------------------------------------------------
+  // ---- the action phase: ActionProcessor.ProcessActions (processor/action_processor.go:36-99) ----
+  // Everything about a move that does not depend on the board as modified by lower player ids is
+  // computed for all players at once on lanes (lane p = player p): coordinate unpack, bounds,
+  // same-tile and adjacency checks of MoveAction.Validate (core/action.go:58-76), tile indices.
   struct ActVec {
     uint32_t meta;  // bits 0-3 static Validate code, bit 4 present (non-nil), bit 5 half
     int ft, tt;     // y*W + x of source / target
@@ -401,15 +467,18 @@ struct PBoard {
     const int dx = fx - tx, dy = fy - ty;
     const int md = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
     uint32_t code = 0u;
-    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;      // action.go:72-76
+    code = (md != 1) ? GVEC_ERR_NOT_ADJACENT : code;      // action.go:72-76 (orthogonal, one step)
     code = (md == 0) ? GVEC_ERR_MOVE_TO_SELF : code;      // :67-69
     code = (!inb) ? GVEC_ERR_INVALID_COORDINATES : code;  // :58-64
     v.meta = code | ((ahi & GVEC_ACT_VALID) ? 16u : 0u) | ((ahi & GVEC_ACT_HALF) ? 32u : 0u);
-    v.ft = __mul24(fy, W) + fx;
+    v.ft = __mul24(fy, W) + fx;  // |coordinates| < 128: full-rate 24-bit multiply
     v.tt = __mul24(ty, W) + tx;
     return v;
   }
 
+  // The state-dependent rest of Validate + core.ApplyMoveAction (core/movement.go:23-89) for
+  // player PID, wave-uniform.  `orders` packs core.ProcessCaptures' output (movement.go:100-118):
+  // byte k = victim | new_owner << 4.
   template <int PID>
   __device__ __forceinline__ void apply_action(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
                                                uint32_t& elim_seen) {
@@ -490,6 +559,8 @@ struct PBoard {
   }
 
   // ---- TurnProcessor.ProcessTurn (turn_processor.go:29-77) ------------------------------------------
+  // acts_lo/hi: lane p holds player p's gvec_action words.  Returns the per-env error code.
+  // Precondition: the caller has checked Engine.gameOver (validateGameState :95-113).
   __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, bool& aborted) {
     aborted = false;
     turn++;  // initializeTurn :124-135
@@ -499,9 +570,10 @@ struct PBoard {
     uint32_t first_err = 0u, elim_seen = 0u;
     uint64_t orders = 0ull;
     int n_orders = 0;
+    // Engine.processActions (engine.go:80-115): PlayerID order == slot order (sort.Slice :39-41)
     const ActVec av = prevalidate(acts_lo, acts_hi);
     const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
-    if (present) {
+    if (present) {  // a turn where nobody moves touches no army
       army_to_lds();
       act_chain<0>(av, first_err, orders, n_orders, elim_seen);
       army_from_lds();
@@ -510,7 +582,7 @@ struct PBoard {
       eliminate(orders, n_orders);
       update_stats();
     }
-    if (first_err) {  // engine.go:111-113 -> turn_processor.go:55-57 (H5)
+    if (first_err) {  // engine.go:111-113 -> turn_processor.go:55-57: production, stats, game-over skipped (H5)
       aborted = true;
       return first_err;
     }
@@ -520,50 +592,53 @@ struct PBoard {
     return 0u;
   }
 
-  // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73); see Board::legal_masks ----
-  template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_targets(uint32_t (&okp)[MPASS], int fd) const {
-    const uint32_t notm = ~mtn & valid;
-    const uint32_t ok_up = upW(notm), ok_dn = dnW(notm);
-    const uint32_t ok_rt = dn1(notm) & ncolL, ok_lf = up1(notm) & ncol0;
-    const uint32_t ok1 = SERIALIZER ? ok_dn : ok_rt, ok2 = SERIALIZER ? ok_lf : ok_dn, ok3 = SERIALIZER ? ok_rt : ok_lf;
+  // ---- EngineInitializer.performInitialSetup (engine_initializer.go:218-225) -----------------
+  __device__ __forceinline__ void initial_setup() {
+    turn = 0;
+    chg = 0u;
+    vch = 0u;
 #pragma unroll
-    for (int k = 0; k < MPASS; ++k) {
-      const int j = lane_id() + 64 * k;
-      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
-      const int addr = (j - d * fd) << 2;  // row 0, column j mod fd
-      const uint32_t g0 = bperm(addr, ok_up), g1 = bperm(addr, ok1), g2 = bperm(addr, ok2), g3 = bperm(addr, ok3);
-      const uint32_t g = (d == 0) ? g0 : (d == 1) ? g1 : (d == 2) ? g2 : g3;
-      okp[k] = (j < 4 * fd) ? g : 0u;
-    }
+    for (int k = 0; k < NR; ++k) vis[k] = 0u;
+    hflags &= ~HF_DONE;
+    update_stats();  // Turn == 0 => full
+    update_fog();    // Turn == 0 => full
+    check_game_over();
   }
+
+  // ---- LegalMoveCalculator.GetLegalActionMask (rules/legal_moves.go:19-73) --------------------
+  // A player's packed mask is FOUR DIRECTION BIT-PLANES of fd dwords each: bit t of plane d = action
+  // (y*W+x)*4 + d of the reference, t = y*W + x.  In the flat domain plane d is
+  //     (listed & owned & army > 1)  &  ok[d]     ("the d-neighbour is on the board, not a mountain")
+  // for all the players of a register at once: m[k][d], row r = player k*PPR + r.  Needs a current gt1.
+  // SERIALIZER = false: Engine.GetLegalActionMask, d = 0 up, 1 right, 2 down, 3 left (H10).
+  // SERIALIZER = true : Serializer.GenerateActionMask (internal/experience/serializer.go:112-176):
+  //   board owner (not the list), army >= 2, no Alive check, d = 0 up, 1 DOWN, 2 LEFT, 3 right (H10).
   template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd, const uint32_t (&okp)[MPASS]) const {
-    uint32_t gt1 = 0u;  // army > 1, in every row
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) scatter_row0(gt1, __builtin_amdgcn_ballot_w64(army[s] > 1), s);
-    gt1 = replicate_row0(gt1);
-    uint32_t src[NR];
+  __device__ __forceinline__ void legal_planes(uint32_t (&m)[NR][4]) const {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1 - all players of the register at once
-      const uint32_t m = SERIALIZER ? (own[k] & gt1) : (lst[k] & own[k] & gt1);
-      src[k] = (SERIALIZER || lane_flag(alive, k)) ? m : 0u;
-    }
-#pragma unroll
-    for (int k2 = 0; k2 < MPASS; ++k2) {
-      const int j = lane_id() + 64 * k2;
-      const int d = (j >= fd ? 1 : 0) + (j >= 2 * fd ? 1 : 0) + (j >= 3 * fd ? 1 : 0);
-      const int c = j - d * fd;
-#pragma unroll
-      for (int p = 0; p < MAXP; ++p) out[p][k2] = bperm((((p % PPR) * ROWL) + c) << 2, src[p / PPR]) & okp[k2];  // cross-lane: unconditional
+      // legal_moves.go :26-28 alive, :37 listed, :41 owner == pid && army > 1
+      const uint32_t s = SERIALIZER ? (own[k] & gt1) : (lst[k] & own[k] & gt1);
+      const uint32_t src = (SERIALIZER || lane_flag(alive, k)) ? s : 0u;
+      m[k][0] = src & ok[0];
+      m[k][1] = src & (SERIALIZER ? ok[2] : ok[1]);
+      m[k][2] = src & (SERIALIZER ? ok[3] : ok[2]);
+      m[k][3] = src & (SERIALIZER ? ok[1] : ok[3]);
     }
   }
-  template <bool SERIALIZER = false>
-  __device__ __forceinline__ void legal_masks(uint32_t (&out)[MAXP][MPASS], int fd) const {
-    uint32_t okp[MPASS];
-    legal_targets<SERIALIZER>(okp, fd);
-    legal_masks<SERIALIZER>(out, fd, okp);
+  // legal_env: this env's [pstride][4*fd] dwords.  Lane (row r, column c) owns dword d*fd + c of player
+  // k*PPR + r: every store instruction writes one direction plane of every player of the register.
+  __device__ __forceinline__ void store_masks(const uint32_t (&m)[NR][4], uint32_t* legal_env, int fd, int pstride) const {
+    const bool in = col() < fd;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int p = lane_player(k);
+      if (in && p < pstride && p < MAXP) {
+        uint32_t* g = legal_env + (size_t)p * (4 * fd) + col();
+#pragma unroll
+        for (int d = 0; d < 4; ++d) g[d * fd] = m[k][d];
+      }
+    }
   }
 };
 

@@ -882,33 +882,43 @@ static uint32_t env_key(uint64_t seed, uint32_t env) {
   return ora_fmix32(ora_fmix32(lo ^ 0x9E3779B9u) + hi * 0x85EBCA77u + env * 0xC2B2AE3Du + 0x27D4EB2Fu);
 }
 
+/* the agent's mixer: two rounds of xorshift + 24-bit multiply (low 32 bits of a 24x24-bit product) */
+static inline uint32_t mul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)); }
+uint32_t ora_amix(uint32_t x) {
+  x ^= x >> 15; x = mul24(x, 0xE8A54Du); x ^= x >> 13; x = mul24(x, 0xAA34A7u); x ^= x >> 15; return x;
+}
+
+/* DESIGN.md "Synthetic inputs": per alive player two hashes h1, h2; no action if (h1 & 0xFFFF) < noop; half move if
+ * (h1 >> 16) < half; with invalid_permille an unchecked move; else the kk-th legal move of
+ * Engine.GetLegalActionMask(p), kk = ((h2 >> 16) * count) >> 16, in the order (t >> 5, d, t & 31): 32-tile blocks
+ * ascending, inside a block direction by direction (up, right, down, left), inside a direction tiles ascending. */
 static void agent_env(const ora_batch* b, const ora_engine* e, uint32_t ek, int32_t invalid_permille,
                       ora_action8* out, uint8_t* scratch) {
   static const int dx[4] = {0, 1, 0, -1}, dy[4] = {-1, 0, 1, 0};
-  int w = e->board->w, h = e->board->h, n4 = w * h * 4;
+  int w = e->board->w, h = e->board->h, n = w * h, n4 = n * 4;
   for (int p = 0; p < b->max_p; p++) memset(&out[p], 0, sizeof(ora_action8));
   for (int p = 0; p < e->num_players; p++) {
     if (!e->players[p].alive) continue;
-    uint32_t h1 = ora_fmix32(ek + (uint32_t)e->turn * 0x9E3779B1u + (uint32_t)p * 0x7F4A7C15u + 0x165667B1u);
+    uint32_t h1 = ora_amix(mul24((uint32_t)p, 0x4A7C15u) + ek + (uint32_t)e->turn * 0x9E3779B1u + 0x165667B1u);
     if ((h1 & 0xFFFFu) < b->agent_noop) continue;             /* no-op, default p ~ 0.1 */
     int half = (h1 >> 16) < b->agent_half;                   /* default p ~ 0.3 */
-    uint32_t h2 = ora_fmix32(h1 ^ 0x68E31DA4u);
-    uint32_t h3 = ora_fmix32(h2 + 0xB5297A4Du);
+    uint32_t h2 = ora_amix(h1 ^ 0x68E31DA4u);
+    uint32_t hi16 = h2 >> 16;
     int t, d;
-    if (invalid_permille > 0 && (int32_t)mulhi32(h3, 1000u) < invalid_permille) {
-      t = (int)mulhi32(h2, (uint32_t)(w * h));               /* unchecked move (H5 stress) */
-      d = (int)(h3 & 3u);
+    if (invalid_permille > 0 && (mul24(h2 & 0xFFFFu, 1000u) >> 16) < (uint32_t)invalid_permille) {
+      t = (int)(mul24(hi16, (uint32_t)n) >> 16);             /* unchecked move (H5 stress) */
+      d = (int)((h1 >> 8) & 3u);
     } else {
       ora_engine_legal_mask(e, p, scratch);
       int cnt = 0;
       for (int i = 0; i < n4; i++) cnt += scratch[i];
       if (cnt == 0) continue;
-      /* k-th legal action in the order of the packed mask: direction plane 0 (up) tile 0.., then 1, 2, 3 */
-      int k = (int)mulhi32(h2, (uint32_t)cnt);
+      int k = (int)(mul24(hi16, (uint32_t)cnt) >> 16);
       t = -1; d = 0;
-      for (int dd = 0; dd < 4 && t < 0; dd++)
-        for (int tt = 0; tt < w * h; tt++)
-          if (scratch[tt * 4 + dd]) { if (k == 0) { t = tt; d = dd; break; } k--; }
+      for (int blk = 0; blk * 32 < n && t < 0; blk++)
+        for (int dd = 0; dd < 4 && t < 0; dd++)
+          for (int tt = blk * 32; tt < blk * 32 + 32 && tt < n; tt++)
+            if (scratch[tt * 4 + dd]) { if (k == 0) { t = tt; d = dd; break; } k--; }
     }
     int x = t % w, y = t / w;
     out[p].from_x = (int8_t)x; out[p].from_y = (int8_t)y;

@@ -164,6 +164,7 @@ int32_t    ora_batch_serializer_mask(ora_batch* b, uint8_t* bits /*[B][max_p][ma
 /* ---- synthetic inputs (the build's own spec; no reference counterpart
  * is reproducible here because Go math/rand is absent) ---- */
 uint32_t   ora_fmix32(uint32_t h);
+uint32_t   ora_amix(uint32_t x);      /* the random agent's mixer (24-bit multiplies) */
 /* random agent: fills actions[num_envs][max_p] for the current state */
 int32_t    ora_batch_set_agent_mix(ora_batch* b, int32_t noop_per_65536, int32_t half_per_65536);
 int32_t    ora_batch_agent_actions(ora_batch* b, uint64_t seed, int32_t invalid_permille, ora_action8* actions, int32_t threads);
