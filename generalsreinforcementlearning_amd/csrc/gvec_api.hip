@@ -44,6 +44,7 @@ struct gvec_handle {
   gvec_action* d_actions = nullptr;
   int32_t* d_err = nullptr;
   int32_t* d_status = nullptr;
+  uint32_t* d_zeros = nullptr;  // row_dw zero dwords (StepArgs::zeros)
   uint32_t agent_noop = 6554u, agent_half = 19661u;  // gvec_set_agent_mix
   unsigned long long* d_counters = nullptr;  // [6]: before[3], after[3]
   uint32_t* d_snap = nullptr;                // experience snapshots [B][snap_dw] (allocated on first use)
@@ -105,6 +106,7 @@ StepArgs base_args(const gvec_handle* h) {
   a.army16 = h->d_army16;
   a.army32 = h->d_army32;
   a.legal = h->d_legal;
+  a.zeros = h->d_zeros;
   a.pool_hdr = h->p_hdr;
   a.pool_rows = h->p_rows;
   a.pool_army16 = h->p_army16;
@@ -199,6 +201,7 @@ int32_t import_planes(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* a
   a.rows = rows;
   a.army16 = army16;
   a.army32 = army32;
+  a.zeros = h->d_zeros;
   a.env_ids = env_ids_dev;
   a.dst_begin = dst_begin;
   a.n = n;
@@ -254,6 +257,8 @@ int32_t allocate_handle(gvec_handle* h, const gvec_config* cfg) {
   HIPCHK(hipMalloc(&h->d_actions, B * h->maxp * sizeof(gvec_action)));
   HIPCHK(hipMalloc(&h->d_err, B * 4));
   HIPCHK(hipMalloc(&h->d_status, 16));
+  HIPCHK(hipMalloc(&h->d_zeros, (size_t)(h->row_dw + 64) * 4));
+  HIPCHK(hipMemset(h->d_zeros, 0, (size_t)(h->row_dw + 64) * 4));
   HIPCHK(hipMalloc(&h->d_counters, 6 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(h->d_rows, 0, B * h->row_dw * 4));
   HIPCHK(hipMemset(h->d_army16, 0, B * h->army_dw * 2));
@@ -348,7 +353,7 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
 int32_t gvec_destroy(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_counters,
+  void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_zeros, h->d_counters,
                   h->d_snap, h->p_hdr, h->p_rows, h->p_army16, h->p_army32};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

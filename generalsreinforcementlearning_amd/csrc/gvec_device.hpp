@@ -89,6 +89,7 @@ struct StepArgs {
   gvec_action* actions_out;    // optional: where the agent records what it played
   int32_t* err;                // [B] or null
   uint32_t* legal;             // [B][pstride][mask_dw]
+  const uint32_t* zeros;  // >= row_dw zero dwords: what the lanes outside a board's bit string load
   const uint32_t* pool_hdr;
   const uint32_t* pool_rows;
   const uint32_t* pool_army16;

@@ -27,14 +27,15 @@ using Turn = PBoard<MAXP, NSLOT>;
 //   (up, right, down, left), inside a plane tiles ascending.  No legal move: no action.
 // All players of a register are sampled at once: lane (row r, column c) counts the legal moves of player
 // r in tile block c, one row-wise prefix scan finds each row's lane, that lane finds its bit.
+// Returns, in lane p, player p's draw: t | d << 10 | act << 12 | half << 13.
 template <int MAXP, int NSLOT>
-__device__ __forceinline__ void agent_sample(const Turn<MAXP, NSLOT>& b, const uint32_t (&m)[Turn<MAXP, NSLOT>::NR][4], uint32_t ek,
-                                             const StepArgs& A, uint32_t& alo, uint32_t& ahi) {
+__device__ __forceinline__ uint32_t agent_sample(const Turn<MAXP, NSLOT>& b, const uint32_t (&m)[Turn<MAXP, NSLOT>::NR][4], uint32_t ek,
+                                                 const StepArgs& A) {
   using T = Turn<MAXP, NSLOT>;
   constexpr int NR = T::NR, PPR = T::PPR, ROWL = T::ROWL;
   const int lane = lane_id();
   const uint32_t sbase = ek + (uint32_t)b.turn * 0x9E3779B1u + 0x165667B1u;  // wave-uniform
-  uint32_t mine = 0u;  // lane p: player p's draw, packed: t | d << 10 | act << 12 | half << 13
+  uint32_t mine = 0u;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     const uint32_t player = (uint32_t)T::lane_player(k);
@@ -65,7 +66,13 @@ __device__ __forceinline__ void agent_sample(const Turn<MAXP, NSLOT>& b, const u
     const uint32_t got = bperm((((lane % PPR) * ROWL) + ROWL - 1) << 2, out);
     mine = (lane / PPR == k) ? got : mine;
   }
-  const bool act = lane < MAXP && (mine & 0x1000u) != 0u;
+  return mine;
+}
+
+// the draw as gvec_action words (gvec_agent_actions, actions_out)
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ void agent_words(const Turn<MAXP, NSLOT>& b, uint32_t mine, uint32_t& alo, uint32_t& ahi) {
+  const bool act = lane_id() < MAXP && (mine & 0x1000u) != 0u;
   const int t = (int)(mine & 0x3FFu), d = (int)((mine >> 10) & 3u);
   const int y = (int)(__umul24((uint32_t)t, (uint32_t)b.recipW) >> 16), x = t - (int)__umul24((uint32_t)y, (uint32_t)b.W);  // t < 1024
   const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
@@ -73,6 +80,27 @@ __device__ __forceinline__ void agent_sample(const Turn<MAXP, NSLOT>& b, const u
                       (((uint32_t)(y + dy) & 0xFFu) << 24);
   alo = act ? lo : 0u;
   ahi = act ? (GVEC_ACT_VALID | ((mine & 0x2000u) ? GVEC_ACT_HALF : 0u)) : 0u;
+}
+
+// the draw as the turn's ActVec, skipping the coordinate round trip through gvec_action: what
+// PBoard::prevalidate would derive from agent_words' output.  A legal move needs no static check (its
+// target is on the board by construction of the mask); an unchecked one (invalid_permille) can only leave
+// the board (core/action.go:58-64) - same tile and adjacency hold for every (tile, direction) pair.
+template <int MAXP, int NSLOT>
+__device__ __forceinline__ typename Turn<MAXP, NSLOT>::ActVec agent_actvec(const Turn<MAXP, NSLOT>& b, uint32_t mine, bool may_be_unchecked) {
+  typename Turn<MAXP, NSLOT>::ActVec v;
+  const bool act = lane_id() < MAXP && (mine & 0x1000u) != 0u;
+  const int t = (int)(mine & 0x3FFu), d = (int)((mine >> 10) & 3u);
+  uint32_t code = 0u;
+  if (may_be_unchecked) {  // wave-uniform
+    const int y = (int)(__umul24((uint32_t)t, (uint32_t)b.recipW) >> 16), x = t - (int)__umul24((uint32_t)y, (uint32_t)b.W);
+    const bool off = (d == 0) ? (y == 0) : (d == 1) ? (x == b.W - 1) : (d == 2) ? (y == b.H - 1) : (x == 0);
+    code = off ? GVEC_ERR_INVALID_COORDINATES : 0u;
+  }
+  v.meta = act ? (code | 16u | ((mine & 0x2000u) ? 32u : 0u)) : 0u;
+  v.ft = t;
+  v.tt = t + ((d == 0) ? -b.W : (d == 1) ? 1 : (d == 2) ? b.W : -1);
+  return v;
 }
 
 // =========================================================================================
@@ -84,6 +112,12 @@ __device__ __forceinline__ void load_board(BT& b, const uint32_t* hdr, const uin
   b.load_army(army);
   b.load_planes(rows, fd);
 }
+template <typename BT>
+__device__ __forceinline__ void load_turn(BT& b, const uint32_t* hdr, const uint32_t* rows, const ArmyCRef& army, int fd, const uint32_t* zeros) {
+  b.load_hdr(hdr);
+  b.load_army(army);
+  b.load_planes(rows, fd, zeros);
+}
 
 // vector-env auto-reset: this step re-deals the env from the board pool (no Go analogue)
 template <int MAXP, int NSLOT, typename BT>
@@ -92,7 +126,7 @@ __device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
   const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
   const int j = (int)__umulhi(hk, (uint32_t)A.pool_size);
-  load_board(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, army_cref<NSLOT>(A.pool_army16, A.pool_army32, j), fd);
+  load_turn(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, army_cref<NSLOT>(A.pool_army16, A.pool_army32, j), fd, A.zeros);
   b.hdr_set(H_EPISODE, episode);
   b.hdr_set(H_CNT_STEPS, cs);
   b.hdr_set(H_CNT_ABORT, ca);
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   B b;
   b.larmy = army_shadow[wave];
   const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD);
+  load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD, A.zeros);
   b.small = !(b.hflags & HF_WIDE);  // one turn from armies <= 65535: every sum of the turn stays below 2^23
   const bool emit = (A.flags & KF_EMIT) != 0u;
   uint32_t m[B::NR][4];
@@ -155,20 +189,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     err = GVEC_ERR_GAME_OVER;  // turn_processor.go:95-113: the engine stays frozen
     changed = false;
   } else {
-    uint32_t alo = 0u, ahi = 0u;
+    typename B::ActVec av;
     if constexpr (AGENT) {
       // the agent's input: the legal-move planes of the resident state, rebuilt from the stored gt1 plane
       // (7 vector instructions; re-reading the 832-byte masks the previous launch wrote would cost more)
       b.template legal_planes<false>(m);
-      agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
-      if (A.actions_out && lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
-    } else if (lane < A.pstride) {
-      const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
-      alo = w.x;
-      ahi = w.y;
+      const uint32_t mine = agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+      av = agent_actvec<MAXP, NSLOT>(b, mine, A.invalid_permille > 0);
+      if (A.actions_out) {
+        uint32_t alo, ahi;
+        agent_words<MAXP, NSLOT>(b, mine, alo, ahi);
+        if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
+      }
+    } else {
+      uint32_t alo = 0u, ahi = 0u;
+      if (lane < A.pstride) {
+        const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
+        alo = w.x;
+        ahi = w.y;
+      }
+      av = b.prevalidate(alo, ahi);
     }
     bool aborted;
-    err = b.turn_step(alo, ahi, A, aborted);
+    err = b.turn_step(av, A, aborted);
     b.refresh_gt1();
     b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
@@ -208,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   B b;
   b.larmy = army_shadow[wave];
   const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd);
+  load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd, A.zeros);
   uint32_t m[B::NR][4];
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
   const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
@@ -219,10 +262,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   for (;;) {
     b.template legal_planes<false>(m);  // the planes of the CURRENT state: the agent's input, the output at the end
     while (k < A.turns && !(b.hflags & HF_DONE)) {
-      uint32_t alo, ahi;
-      agent_sample<MAXP, NSLOT>(b, m, ek, A, alo, ahi);
+      const uint32_t mine = agent_sample<MAXP, NSLOT>(b, m, ek, A);
       bool aborted;
-      err = b.turn_step(alo, ahi, A, aborted);
+      err = b.turn_step(agent_actvec<MAXP, NSLOT>(b, mine, A.invalid_permille > 0), A, aborted);
       n_steps += 1u;
       n_abort += aborted ? 1u : 0u;
       n_done += (b.hflags & HF_DONE) ? 1u : 0u;
@@ -259,13 +301,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   if (env >= A.num_envs) return;
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd, A.zeros);
   uint32_t m[B::NR][4];
   if constexpr (MODE == 2) b.template legal_planes<true>(m);
   else b.template legal_planes<false>(m);
   if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
-    if (!(b.hflags & HF_DONE)) agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A, alo, ahi);
+    if (!(b.hflags & HF_DONE)) agent_words<MAXP, NSLOT>(b, agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A), alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
   } else {
     b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
@@ -284,7 +326,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void setup_kernel(ImportArgs 
   if (env < 0 || env >= A.dst_envs) return;  // reported by the import kernel
   B b;
   b.larmy = nullptr;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd, A.zeros);
   if (!(b.hflags & HF_SETUP)) return;  // this env's input was rejected: left as it was
   b.hflags &= ~HF_SETUP;
   b.initial_setup();

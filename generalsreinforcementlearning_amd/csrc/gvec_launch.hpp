@@ -38,6 +38,7 @@ struct ImportArgs {
   const int32_t* s_army_count;
   const int32_t* s_general_idx;
   int32_t stride, max_p, max_w, max_h, fd, row_dw;
+  const uint32_t* zeros;  // see StepArgs::zeros (setup_kernel)
   int32_t dst_envs;  // envs in the destination arrays: env ids are checked against it on the device
   uint32_t fresh;  // 1: start from a blank engine (reset); 0: poke the resident record
   uint32_t init;   // 1: run performInitialSetup after the import

@@ -158,33 +158,31 @@ struct PBoard {
   }
 
   // ---- planes: one load per packed register (PPR planes at once), shared planes replicated ------------
-  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd) {
+  // Lanes that hold no dword of the bit string (column >= fd, or a row without a player) must read as zero.
+  // They are pointed at `zeros` - a block of at least row_dw zero dwords - so every plane is ONE load with an
+  // immediate offset and no select on the data (16 selects per board otherwise).
+  __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd, const uint32_t* zeros) {
     const bool in = col() < fd;
-    const uint32_t* gp = rows_env + (in ? row() * fd + col() : 0);  // packed: plane (base + row), dword col
-    const uint32_t* gs = rows_env + (in ? col() : 0);               // shared: every row reads the same dwords
+    const uint32_t* gs = in ? rows_env + col() : zeros;  // shared: every row reads the same dwords
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const bool on = in && (k * PPR + row() < MAXP);
-      const uint32_t a = gp[(PL::OWN + k * PPR) * fd], b = gp[(PL::LST + k * PPR) * fd], c = gp[(PL::VIS + k * PPR) * fd];
-      own[k] = on ? a : 0u;
-      lst[k] = on ? b : 0u;
-      vis[k] = on ? c : 0u;
+      const uint32_t* gp = on ? rows_env + (row() * fd + col()) : zeros;  // packed: plane (base + row), dword col
+      own[k] = gp[(PL::OWN + k * PPR) * fd];
+      lst[k] = gp[(PL::LST + k * PPR) * fd];
+      vis[k] = gp[(PL::VIS + k * PPR) * fd];
     }
-    auto ld = [&](int plane) {
-      const uint32_t v = gs[plane * fd];
-      return in ? v : 0u;
-    };
-    chg = ld(PL::CHG);
-    vch = ld(PL::VCH);
-    gt1 = ld(PL::GT1);
-    gen = ld(PL::GEN);
-    city = ld(PL::CITY);
-    mtn = ld(PL::MTN);
-    valid = ld(PL::VALID);
-    ncol0 = ld(PL::NCOL0);
-    ncolL = ld(PL::NCOLL);
+    chg = gs[PL::CHG * fd];
+    vch = gs[PL::VCH * fd];
+    gt1 = gs[PL::GT1 * fd];
+    gen = gs[PL::GEN * fd];
+    city = gs[PL::CITY * fd];
+    mtn = gs[PL::MTN * fd];
+    valid = gs[PL::VALID * fd];
+    ncol0 = gs[PL::NCOL0 * fd];
+    ncolL = gs[PL::NCOLL * fd];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) ok[d] = ld(PL::OK + d);
+    for (int d = 0; d < 4; ++d) ok[d] = gs[(PL::OK + d) * fd];
   }
   // The planes from GEN on change only when the env is re-dealt (with_types).
   __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
@@ -562,6 +560,10 @@ struct PBoard {
   // acts_lo/hi: lane p holds player p's gvec_action words.  Returns the per-env error code.
   // Precondition: the caller has checked Engine.gameOver (validateGameState :95-113).
   __device__ __forceinline__ uint32_t turn_step(uint32_t acts_lo, uint32_t acts_hi, const StepArgs& A, bool& aborted) {
+    return turn_step(prevalidate(acts_lo, acts_hi), A, aborted);
+  }
+  // av: lane p holds player p's move after the static checks (prevalidate, or the on-device agent's own output)
+  __device__ __forceinline__ uint32_t turn_step(const ActVec& av, const StepArgs& A, bool& aborted) {
     aborted = false;
     turn++;  // initializeTurn :124-135
     update_fog();
@@ -571,7 +573,6 @@ struct PBoard {
     uint64_t orders = 0ull;
     int n_orders = 0;
     // Engine.processActions (engine.go:80-115): PlayerID order == slot order (sort.Slice :39-41)
-    const ActVec av = prevalidate(acts_lo, acts_hi);
     const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
     if (present) {  // a turn where nobody moves touches no army
       army_to_lds();
