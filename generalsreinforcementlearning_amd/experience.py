@@ -57,20 +57,30 @@ class VecExperienceCollector:
         self.e.experience_begin()
 
     def after_step(self, actions):
-        """-> dict of arrays over the K (env, player) pairs that acted (collector.go:33-37)."""
+        """-> dict over the K (env, player) pairs that acted (collector.go:33-37).  Every experience is shaped by
+        ITS env's board (TensorState.shape = [9, Board.H, Board.W], collector.go:64,71): in a padded batch of
+        mixed sizes `state` / `next_state` / `action_mask` are lists of per-experience arrays; when every env has
+        the same size they are stacked arrays, as before."""
         e = self.e
         acted = (np.asarray(actions["flags"]) & ACT_VALID) != 0           # [B, P]
         env, player = np.nonzero(acted)
         rewards, done = e.experience_rewards()                             # CalculateReward, IsGameOver  :47,56
         nxt = e.observe(-1)                                                # StateToTensor(currState, player) :44
         st = e.game_state(fields=("turn", "width", "height"))
-        shape = (9, e.max_h, e.max_w)
+        w, h = st["width"][env].astype(np.int64), st["height"][env].astype(np.int64)
+        # observe / serializer_mask lay an env's tensor out with ITS OWN row pitch at the start of the padded slot
+        # (include/generals_vec.h: index c*H*W + y*W + x; mask bit t = y*W + x of plane d)
+        def tensors(src):
+            return [src[ev, pl, : 9 * hh * ww].reshape(9, hh, ww) for ev, pl, ww, hh in zip(env, player, w, h)]
+        state, next_state = tensors(self._state), tensors(nxt)
+        masks = [unpack_legal_bits(self._mask[ev, pl], int(ww), int(hh)) for ev, pl, ww, hh in zip(env, player, w, h)]
+        action = np.array([action_to_index(actions[ev, pl], int(ww)) for ev, pl, ww in zip(env, player, w)], np.int32).reshape(-1)
+        if len(env) and (w == w[0]).all() and (h == h[0]).all():
+            state, next_state, masks = np.stack(state), np.stack(next_state), np.stack(masks)
         return {
-            "env": env, "player_id": player.astype(np.int32), "turn": st["turn"][env],
-            "state": self._state[env, player].reshape((-1,) + shape), "next_state": nxt[env, player].reshape((-1,) + shape),
-            "action": action_to_index(actions[env, player], e.max_w).astype(np.int32),
-            "reward": rewards[env, player], "done": done[env],
-            "action_mask": unpack_legal_bits(self._mask[env, player], e.max_w, e.max_h),
+            "env": env, "player_id": player.astype(np.int32), "turn": st["turn"][env], "width": w, "height": h,
+            "state": state, "next_state": next_state, "action": action,
+            "reward": rewards[env, player], "done": done[env], "action_mask": masks,
         }
 
     def as_dicts(self, batch):

@@ -339,6 +339,63 @@ void ora_engine_update_fog(ora_engine* e) {                 /* visibility.go:11-
   perform_incremental_visibility_update(e);
 }
 
+/* ---- visibility.go:19-144: the LEGACY twin of the fog update (features.use_optimized_visibility = false) ----
+ * Restated separately, in its own idiom (Tile.SetVisible per player and tile, no bit masks, its own loop
+ * nests), as a second opinion on the optimized restatement above: the two must leave identical
+ * VisibleBitfields after every update - same thresholds (visibility.go:24-25), same "affected = board owners
+ * within 5x5" (:99-117), same re-lighting from OwnedTiles (:85-93).  They differ in ONE observable only:
+ * this path goes through Tile.SetVisible and therefore accumulates DiscoveredBitfield (core/board.go:57-60),
+ * the optimized path writes VisibleBitfield directly and leaves it 0.  Test-only. */
+static void legacy_set_visibility_around(ora_engine* e, int tile_idx, int pid) {   /* visibility.go:119-131 */
+  int x = tile_idx % e->board->w, y = tile_idx / e->board->w;
+  for (int dx = -1; dx <= 1; dx++)
+    for (int dy = -1; dy <= 1; dy++) {
+      int nx = x + dx, ny = y + dy;
+      if (nx >= 0 && nx < e->board->w && ny >= 0 && ny < e->board->h)
+        ora_tile_set_visible(&e->board->t[ny * e->board->w + nx], pid, 1);
+    }
+}
+static void legacy_clear_visibility_around(ora_engine* e, int tile_idx) {          /* visibility.go:133-146 */
+  int x = tile_idx % e->board->w, y = tile_idx / e->board->w;
+  for (int dx = -1; dx <= 1; dx++)
+    for (int dy = -1; dy <= 1; dy++) {
+      int nx = x + dx, ny = y + dy;
+      if (nx >= 0 && nx < e->board->w && ny >= 0 && ny < e->board->h)
+        for (int pid = 0; pid < e->num_players; pid++) ora_tile_set_visible(&e->board->t[ny * e->board->w + nx], pid, 0);
+    }
+}
+void ora_engine_update_fog_legacy(ora_engine* e) {
+  if (!e->fog) return;                                                              /* :19-21 */
+  int n = e->board->w * e->board->h;
+  if (e->turn == 0 || e->vis_changed.count > n / 10) {                              /* :24-28 performFullVisibilityUpdate :34-54 */
+    for (int i = 0; i < n; i++)
+      for (int pid = 0; pid < e->num_players; pid++) ora_tile_set_visible(&e->board->t[i], pid, 0);
+    for (int pid = 0; pid < e->num_players; pid++) {
+      if (!e->players[pid].alive) continue;
+      for (int k = 0; k < e->players[pid].owned.n; k++) legacy_set_visibility_around(e, e->players[pid].owned.v[k], pid);
+    }
+    return;
+  }
+  /* performIncrementalVisibilityUpdate :57-95 */
+  int affected[32]; for (int i = 0; i < 32; i++) affected[i] = 0;
+  for (int t = 0; t < n; t++) {                                                     /* collectAffectedPlayers :99-117 */
+    if (!e->vis_changed.bits[t]) continue;
+    int x = t % e->board->w, y = t / e->board->w;
+    for (int dx = -2; dx <= 2; dx++)
+      for (int dy = -2; dy <= 2; dy++) {
+        int nx = x + dx, ny = y + dy;
+        if (nx >= 0 && nx < e->board->w && ny >= 0 && ny < e->board->h) {
+          int owner = e->board->t[ny * e->board->w + nx].owner;
+          if (owner >= 0 && owner < e->num_players) affected[owner] = 1;
+        }
+      }
+  }
+  for (int t = 0; t < n; t++) if (e->vis_changed.bits[t]) legacy_clear_visibility_around(e, t);   /* :75-81 */
+  for (int pid = 0; pid < e->num_players; pid++) {                                  /* :85-93 */
+    if (!affected[pid] || !e->players[pid].alive) continue;
+    for (int k = 0; k < e->players[pid].owned.n; k++) legacy_set_visibility_around(e, e->players[pid].owned.v[k], pid);
+  }
+}
 void ora_engine_player_visibility(const ora_engine* e, int32_t player, uint8_t* visible, uint8_t* fog) { /* :166-195 */
   int n = e->board->w * e->board->h;
   if (visible) memset(visible, 0, (size_t)n);
@@ -1089,3 +1146,24 @@ int64_t ora_batch_rollout(ora_batch* b, int32_t turns, uint64_t seed, int32_t in
   }
   return steps;
 }
+
+/* For every env of a batch: what the LEGACY update would make of the state the next Step will start from
+ * (Turn + 1, visibility.go:11-32 runs inside initializeTurn, turn_processor.go:124-135).  visible[B][stride]
+ * (bit p), discovered[B][stride]; the batch itself is not touched. */
+int32_t ora_batch_next_fog_legacy(ora_batch* b, uint8_t* visible, uint8_t* discovered) {
+  for (int id = 0; id < b->num_envs; id++) {
+    ora_engine* c = ora_engine_clone(b->env[id]);
+    int n = c->board->w * c->board->h;
+    c->turn += 1;
+    ora_engine_update_fog_legacy(c);
+    memset(visible + (size_t)id * (size_t)b->stride, 0, (size_t)b->stride);
+    memset(discovered + (size_t)id * (size_t)b->stride, 0, (size_t)b->stride);
+    for (int t = 0; t < n; t++) {
+      visible[(size_t)id * (size_t)b->stride + (size_t)t] = (uint8_t)(c->board->t[t].visible & 0xFFu);
+      discovered[(size_t)id * (size_t)b->stride + (size_t)t] = (uint8_t)(c->board->t[t].discovered & 0xFFu);
+    }
+    ora_engine_free(c);
+  }
+  return 0;
+}
+

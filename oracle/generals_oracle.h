@@ -93,6 +93,9 @@ void        ora_engine_initial_setup(ora_engine* e);
 int32_t     ora_engine_step(ora_engine* e, const ora_move* actions, int32_t n);
 void        ora_engine_update_player_stats(ora_engine* e);      /* stats.go:8-30 */
 void        ora_engine_update_fog(ora_engine* e);               /* visibility.go:11-16 -> visibility_optimized.go:16-30 */
+/* visibility.go:19-144: the legacy twin of the fog update, restated independently (test-only cross-check:
+ * identical VisibleBitfield, plus the DiscoveredBitfield the optimized path never sets - SURVEY H9) */
+void        ora_engine_update_fog_legacy(ora_engine* e);
 void        ora_engine_process_production(ora_engine* e);       /* production_manager.go:26-73 with gs.Turn */
 void        ora_engine_check_game_over(ora_engine* e);          /* engine.go:160-194 */
 /* Engine.GetLegalActionMask (engine.go:271-280 -> rules/legal_moves.go:19-73); mask has w*h*4 bytes */
@@ -142,6 +145,9 @@ typedef struct ora_state_view {
 } ora_state_view;
 int32_t    ora_batch_read_state(ora_batch* b, int32_t env_begin, int32_t n, const ora_state_view* v);
 int32_t    ora_batch_write_state(ora_batch* b, int32_t env_begin, int32_t n, const ora_state_view* v);
+
+/* what the LEGACY fog update would leave after the next turn's initializeTurn, for every env (batch untouched) */
+int32_t    ora_batch_next_fog_legacy(ora_batch* b, uint8_t* visible /*[B][stride]*/, uint8_t* discovered /*[B][stride]*/);
 
 /* ---- internal/experience: serializer + rewards ---- */
 /* GameState.Clone (state.go:37-70) */

@@ -132,6 +132,7 @@ def lib():
     L.ora_batch_set_pool.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, i32p, i32p, i32p]
     L.ora_batch_rollout.restype = C.c_int64
     L.ora_batch_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
+    L.ora_batch_next_fog_legacy.argtypes = [C.c_void_p, u8p, u8p]
     L.ora_engine_clone.restype = C.c_void_p
     L.ora_engine_clone.argtypes = [C.c_void_p]
     L.ora_state_to_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
@@ -345,6 +346,14 @@ class OracleBatch:
         v = make_view(StateView, arrays)
         rc = self.L.ora_batch_write_state(self.b, env_begin, n, C.byref(v))
         assert rc == 0, rc
+
+    def next_fog_legacy(self):
+        """(visible, discovered) [B][stride]: what the LEGACY fog update (visibility.go:19-144) makes of the
+        state the next step starts from."""
+        v = np.zeros((self.B, self.stride), np.uint8)
+        d = np.zeros((self.B, self.stride), np.uint8)
+        self.L.ora_batch_next_fog_legacy(self.b, _ptr(v, u8p), _ptr(d, u8p))
+        return v, d
 
     def experience_begin(self):
         self.L.ora_batch_experience_begin(self.b)
