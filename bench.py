@@ -149,6 +149,15 @@ class _NullEngine:
     def export_records(self, ptr, lo, n):
         return None
 
+    def experience_begin_range(self, lo, n):
+        return None
+
+    def experience_records(self, ptr, actions=None, env_begin=0, n=None, env_id_base=0):
+        return None
+
+    def experience_record_bytes(self):
+        return self.rec
+
 
 def rehearse_cpu(args):
     """The N > 1 choreography of main() on CPU tensors with the gloo backend: rendezvous from the
@@ -165,15 +174,18 @@ def rehearse_cpu(args):
     B, total, mode = shard_plan(args, world, rank)
     eng = _NullEngine(64)
     ge = min(args.gather_envs, B)
-    rg = RecordGather(ge * eng.state_bytes_per_env(), torch.device("cpu"), dst=0) if ge > 0 else None
+    rg = RecordGather(ge * eng.experience_record_bytes(), torch.device("cpu"), dst=0) if ge > 0 else None
     got = 0
     for k in range(args.warmup):
         eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
     dist.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if rg is not None:
+            eng.experience_begin_range(0, ge)
         eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
         if rg is not None:
+            eng.experience_records(rg.send.data_ptr(), None, 0, ge, rank * B)
             rg.send.fill_((rank * 31 + k) % 251)
             out = rg.gather()
             if rank == 0:
@@ -245,26 +257,30 @@ def main():
 
     rgs, side, slab_free = None, None, None
     if dist is not None and args.gather_envs > 0:
-        # the one real exchange step of the path: compact experience/state slabs -> rank 0 (StreamAggregator side).
-        # Two slabs alternate so step k+1's export never waits for step k's gather on the side stream.
+        # the one real exchange step of the path: compact EXPERIENCE RECORDS -> rank 0 (the StreamAggregator side,
+        # internal/grpc/gameserver/stream_aggregator.go:75-155), expanded there (experience.decode_records).
+        # Two slabs alternate so step k+1's records never wait for step k's gather on the side stream.
         from generalsreinforcementlearning_amd.sharding import RecordGather
         ge = min(args.gather_envs, B)
-        rgs = [RecordGather(ge * eng.state_bytes_per_env(), dev, dst=0) for _ in range(2)]
+        rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)]
         slab_free = [None, None]
         side = torch.cuda.Stream()
+        eng.record_agent_actions(True)                            # the record needs the moves the device agent played
 
     def one_step(k):
+        if rgs is not None:
+            ge = min(args.gather_envs, B)
+            lo = (k * ge) % max(1, B - ge + 1)
+            eng.experience_begin_range(lo, ge)                    # captureStateForExperience for the sampled slice
         eng.rollout(1, seed, 0, fused=False, want_stats=False)
         if rgs is not None:
             i = k & 1
-            ge = min(args.gather_envs, B)
-            lo = (k * ge) % max(1, B - ge + 1)
             if slab_free[i] is not None:
-                stream.wait_event(slab_free[i])                  # slab i was last read by the gather of step k-2
-            eng.export_records(rgs[i].send.data_ptr(), lo, ge)   # on the compute stream, after this step's kernel
+                stream.wait_event(slab_free[i])                   # slab i was last read by the gather of step k-2
+            eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, rank * B)   # compute stream, after this step's kernel
             side.wait_stream(stream)
             with torch.cuda.stream(side):
-                rgs[i].gather()                                   # RCCL gather over xGMI, overlapped with the next step
+                rgs[i].gather()                                    # RCCL gather over xGMI, overlapped with the next step
                 slab_free[i] = side.record_event()
 
     def sync_all():
@@ -312,6 +328,17 @@ def main():
         fused = {"turns_per_launch": kf, "env_steps_per_s_per_gpu": B * kf / (f0.elapsed_time(f1) / 1e3),
                  "note": "same turns with board state kept in registers/LDS across one launch (gvec_rollout fused=1)"}
 
+    gathered = None
+    if rgs is not None and rank == 0:
+        # the consumer side, outside the timed region: expand the last gathered slabs into Experience fields
+        from generalsreinforcementlearning_amd.experience import decode_records
+        torch.cuda.synchronize()
+        lay = eng.experience_record_layout()
+        last = rgs[(args.warmup + args.steps - 1) & 1].recv
+        decs = [decode_records(t.cpu().numpy(), lay, drop_invalid=True) for t in last]
+        gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_step": min(args.gather_envs, B),
+                    "experiences_decoded_last_step": int(sum(len(d["env"]) for d in decs)),
+                    "ranks_seen": sorted({int(e) // B for d in decs for e in d["env"]})}
     if rank == 0:
         n = world
         abytes = algorithmic_bytes(W, H, P, True)
@@ -351,6 +378,8 @@ def main():
                          "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
                          "units_per_launch": B, "kernel_ms": kernel_ms},
         }
+        if gathered:
+            out["experience_gather"] = gathered
         if fused:
             out["fused_rollout"] = fused
         if n == 1 and not args.no_cpu_baseline:

@@ -57,7 +57,12 @@ SYMBOLS = {
     "gvec_set_agent_mix": (_i32, [_vp, _i32, _i32]),
     "gvec_agent_actions": (_i32, [_vp, _u64, _i32, _vp, _i32]),
     "gvec_experience_begin": (_i32, [_vp]),
+    "gvec_experience_begin_range": (_i32, [_vp, _i32, _i32]),
     "gvec_experience_rewards": (_i32, [_vp, _vp, _vp, _i32]),
+    "gvec_experience_record_layout": (_i32, [_vp, C.POINTER(C.c_int32)]),
+    "gvec_experience_record_bytes": (_i32, [_vp]),
+    "gvec_experience_records": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gvec_record_agent_actions": (_i32, [_vp, _i32]),
     "gvec_observe": (_i32, [_vp, _i32, _vp, _i32]),
     "gvec_serializer_mask": (_i32, [_vp, _vp, _i32]),
     "gvec_export_records": (_i32, [_vp, _i32, _i32, _vp]),

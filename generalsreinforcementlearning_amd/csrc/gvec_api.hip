@@ -48,7 +48,8 @@ struct gvec_handle {
   uint32_t agent_noop = 6554u, agent_half = 19661u;  // gvec_set_agent_mix
   unsigned long long* d_counters = nullptr;  // [6]: before[3], after[3]
   uint32_t* d_snap = nullptr;                // experience snapshots [B][snap_dw] (allocated on first use)
-  int snap_dw = 0;
+  int snap_dw = 0, record_dw = 0;
+  bool record_actions = false;               // per-turn rollouts write the agent's moves into d_actions
   uint32_t* p_hdr = nullptr;
   uint32_t* p_rows = nullptr;
   uint32_t* p_army16 = nullptr;
@@ -664,6 +665,7 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
     if (!h->legal_valid) RET_IF(refresh_legal(h));  // the per-turn agent samples from the mask buffer
     a.turns = 1;
     a.flags |= KF_LMVALID;
+    if (h->record_actions) a.actions_out = h->d_actions;  // gvec_record_agent_actions: what the agent played
     for (int k = 0; k < turns; ++k) HIPCHK(launch_step(h->var, a, h->stream));
   }
   if (turns > 0) h->legal_valid = true;
@@ -720,21 +722,38 @@ static ExperienceArgs exp_args(gvec_handle* h) {
   a.fd = h->fd;
   a.row_dw = h->row_dw;
   a.snap_dw = h->snap_dw;
+  a.record_dw = h->record_dw;
   a.pstride = h->maxp;
   a.stride = h->stride;
   a.player = -1;
   return a;
 }
 
+static int32_t ensure_snapshots(gvec_handle* h) {
+  if (!h->d_snap) {
+    experience_layout(h->var, h->fd, &h->snap_dw, &h->record_dw);
+    HIPCHK(hipMalloc(&h->d_snap, (size_t)h->cfg.num_envs * h->snap_dw * 4));
+    HIPCHK(hipMemset(h->d_snap, 0, (size_t)h->cfg.num_envs * h->snap_dw * 4));
+  }
+  return GVEC_OK;
+}
+
+int32_t gvec_experience_begin_range(gvec_handle* h, int32_t env_begin, int32_t n) {
+  if (!h) return GVEC_E_INVALID;
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0) return GVEC_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RET_IF(ensure_snapshots(h));
+  ExperienceArgs a = exp_args(h);
+  a.env_begin = env_begin;
+  a.num_envs = n;
+  HIPCHK(launch_snapshot(h->var, a, h->stream));
+  return GVEC_OK;
+}
+
 int32_t gvec_experience_begin(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  if (!h->d_snap) {
-    h->snap_dw = (int)round_up((size_t)h->var.maxp * h->fd + 2 * h->var.maxp + 2, 4);
-    HIPCHK(hipMalloc(&h->d_snap, (size_t)h->cfg.num_envs * h->snap_dw * 4));
-  }
-  HIPCHK(launch_snapshot(h->var, exp_args(h), h->stream));
-  return GVEC_OK;
+  return gvec_experience_begin_range(h, 0, h->cfg.num_envs);
 }
 
 int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, int32_t mem) {
@@ -753,6 +772,60 @@ int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, i
   RET_IF(copy_out(h, br, rewards, B * h->maxp, mem));
   RET_IF(copy_out(h, bd, done, B, mem));
   if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_experience_record_layout(gvec_handle* h, int32_t* out8) {
+  if (!h || !out8) return GVEC_E_INVALID;
+  int snap_dw = 0, record_dw = 0;
+  experience_layout(h->var, h->fd, &snap_dw, &record_dw);
+  out8[0] = record_dw;          // dwords per record
+  out8[1] = h->var.maxp;        // player slots of the layout (>= max_players)
+  out8[2] = h->fd;              // dwords per bit-plane
+  out8[3] = h->var.nslot;       // 64-tile army slots
+  out8[4] = h->maxp;            // max_players of the handle
+  out8[5] = h->stride;          // max_width * max_height
+  out8[6] = 0;
+  out8[7] = 0;
+  return GVEC_OK;
+}
+
+int32_t gvec_experience_record_bytes(gvec_handle* h) {
+  int32_t l[8];
+  const int32_t rc = gvec_experience_record_layout(h, l);
+  return rc < 0 ? rc : l[0] * 4;
+}
+
+int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int32_t mem, int32_t env_begin, int32_t n,
+                                int32_t env_id_base, void* dst_device) {
+  if (!h || !dst_device) return GVEC_E_INVALID;
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (!h->d_snap) {
+    set_err("gvec_experience_records without a preceding gvec_experience_begin");
+    return GVEC_E_INVALID;
+  }
+  if (n == 0) return GVEC_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  ExperienceArgs a = exp_args(h);
+  if (!actions) {
+    a.actions = h->d_actions;  // the last gvec_step (host mode) / recorded device-agent turn
+  } else if (mem == GVEC_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(h->d_actions, actions, (size_t)h->cfg.num_envs * h->maxp * sizeof(gvec_action), hipMemcpyHostToDevice, h->stream));
+    a.actions = h->d_actions;
+  } else {
+    a.actions = actions;
+  }
+  a.env_begin = env_begin;
+  a.num_envs = n;
+  a.env_id_base = env_id_base;
+  a.records = reinterpret_cast<uint32_t*>(dst_device);
+  HIPCHK(launch_experience_records(h->var, a, h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
+  if (!h) return GVEC_E_INVALID;
+  h->record_actions = on != 0;
   return GVEC_OK;
 }
 

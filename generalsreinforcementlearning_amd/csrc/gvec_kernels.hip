@@ -337,53 +337,89 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void setup_kernel(ImportArgs 
 // =========================================================================================
 // internal/experience: snapshot (GameState.Clone before the step), rewards, observation tensor
 // =========================================================================================
+// Snapshot of env e (snap_dw dwords): what the reward AND the experience record need of the state before the
+// step - prev own planes [MAXP][fd] | prev vis planes [MAXP][fd] | Serializer.GenerateActionMask(prev) as four
+// direction planes per player [MAXP][4][fd] | prev armies as u16, tile t at halfword t, saturated to [0, 65535]
+// (StateToTensor clamps army / 1000 at 1, serializer.go:82-85: saturation is exact for it) [NSLOT*32] |
+// tail: territory [MAXP], armies [MAXP], turn, W | H << 8.
+template <int MAXP, int NSLOT>
+struct SnapLayout {
+  int fd;
+  __host__ __device__ int own() const { return 0; }
+  __host__ __device__ int vis() const { return MAXP * fd; }
+  __host__ __device__ int mask() const { return 2 * MAXP * fd; }
+  __host__ __device__ int army() const { return 6 * MAXP * fd; }
+  __host__ __device__ int tail() const { return 6 * MAXP * fd + NSLOT * 32; }
+  __host__ __device__ int total() const { return (tail() + 2 * MAXP + 2 + 3) / 4 * 4; }
+};
+
+// Tile.Army as the u16 a tensor consumer needs: lane l of slot s is tile 64s + l
+template <int NSLOT>
+__device__ __forceinline__ void store_army_sat16(const int32_t (&army)[NSLOT], uint32_t* dst) {
+  uint16_t* h = reinterpret_cast<uint16_t*>(dst);
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int32_t a = army[s];
+    h[64 * s + lane_id()] = (uint16_t)(a < 0 ? 0 : (a > 65535 ? 65535 : a));
+  }
+}
+
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void snapshot_kernel(ExperienceArgs A) {
   using B = Board<MAXP, NSLOT>;
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
-  if (env >= A.num_envs) return;
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.num_envs) return;
+  const int env = A.env_begin + i;
   B b;
   load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  const SnapLayout<MAXP, NSLOT> L{A.fd};
   uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
   uint32_t tail = 0u;  // lane p: territory, lane MAXP+p: armies, lane 2*MAXP: turn, +1: W|H<<8
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
-    if (lane < A.fd) sn[p * A.fd + lane] = b.own[p];
+    if (lane < A.fd) {
+      sn[L.own() + p * A.fd + lane] = b.own[p];
+      sn[L.vis() + p * A.fd + lane] = b.vis[p];
+      // Serializer.GenerateActionMask (serializer.go:112-176): board owner, army >= 2, no Alive check;
+      // d = 0 up, 1 DOWN, 2 LEFT, 3 right
+      const uint32_t src = b.own[p] & b.gt1;
+      uint32_t* m = sn + L.mask() + p * 4 * A.fd + lane;
+      m[0 * A.fd] = src & b.ok[0];
+      m[1 * A.fd] = src & b.ok[2];
+      m[2 * A.fd] = src & b.ok[3];
+      m[3 * A.fd] = src & b.ok[1];
+    }
     const int32_t terr = b.count(b.own[p]), arm = b.army_sum(b.own[p]);
     tail = (lane == p) ? (uint32_t)terr : tail;
     tail = (lane == MAXP + p) ? (uint32_t)arm : tail;
   }
+  store_army_sat16<NSLOT>(b.army, sn + L.army());
   tail = (lane == 2 * MAXP) ? (uint32_t)b.turn : tail;
   tail = (lane == 2 * MAXP + 1) ? ((uint32_t)b.W | ((uint32_t)b.H << 8)) : tail;
-  if (lane < 2 * MAXP + 2) sn[MAXP * A.fd + lane] = tail;
+  if (lane < 2 * MAXP + 2) sn[L.tail() + lane] = tail;
 }
 
 // CalculateRewardWithConfig (internal/experience/rewards.go:45-85) with DefaultRewardConfig (:23-37);
 // prev = the snapshot, cur = the resident state.  float32 arithmetic in the reference's order,
-// compiled with -ffp-contract=off (Go on amd64 does not fuse multiply-add).
+// compiled with -ffp-contract=off (Go on amd64 does not fuse multiply-add).  Lane p receives player p's reward.
 template <int MAXP, int NSLOT>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(ExperienceArgs A) {
-  using B = Board<MAXP, NSLOT>;
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
-  if (env >= A.num_envs) return;
-  B b;
-  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
-  const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
-  const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[MAXP * A.fd + lane] : 0u;
+__device__ __forceinline__ float compute_rewards(const Board<MAXP, NSLOT>& b, const uint32_t* sn, int fd, bool& over, bool& comparable) {
+  const int lane = lane_id();
+  const SnapLayout<MAXP, NSLOT> L{fd};
+  const uint32_t tail = (lane < 2 * MAXP + 2) ? sn[L.tail() + lane] : 0u;
   const int prev_turn = (int)rdlane(tail, 2 * MAXP);
   const uint32_t prev_dims = rdlane(tail, 2 * MAXP + 1);
   // a board re-dealt by auto-reset (or not stepped) has no meaningful predecessor: reward 0
-  const bool comparable = prev_dims == ((uint32_t)b.W | ((uint32_t)b.H << 8)) && b.turn > prev_turn;
+  comparable = prev_dims == ((uint32_t)b.W | ((uint32_t)b.H << 8)) && b.turn > prev_turn;
   const int na = __builtin_popcount(b.alive);
-  const bool over = na <= 1;                                     // GameState.IsGameOver (state.go:73-82)
+  over = na <= 1;                                                // GameState.IsGameOver (state.go:73-82)
   const int winner = (na == 1) ? (31 - __builtin_clz(b.alive)) : -1;  // GameState.GetWinner (state.go:85-100)
   uint32_t prev_own[MAXP], prev_any = 0u;
   int32_t cur_arm[MAXP], total = 0;
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
-    prev_own[p] = (lane < A.fd) ? sn[p * A.fd + lane] : 0u;
+    prev_own[p] = (lane < fd) ? sn[L.own() + p * fd + lane] : 0u;
     prev_any |= prev_own[p];
     cur_arm[p] = b.army_sum(b.own[p]);
     total += cur_arm[p];
@@ -412,8 +448,105 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(Experienc
     r = (comparable && p < b.P) ? r : 0.0f;
     rv = (lane == p) ? r : rv;
   }
-  if (lane < A.pstride) A.rewards[(size_t)env * A.pstride + lane] = rv;
-  if (A.done && lane == 0) A.done[env] = (uint8_t)(over ? 1 : 0);
+  return rv;
+}
+
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rewards_kernel(ExperienceArgs A) {
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.num_envs) return;
+  const int env = A.env_begin + i;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  bool over, comparable;
+  const float rv = compute_rewards<MAXP, NSLOT>(b, A.snap + (size_t)env * A.snap_dw, A.fd, over, comparable);
+  if (lane < A.pstride) A.rewards[(size_t)i * A.pstride + lane] = rv;
+  if (A.done && lane == 0) A.done[i] = (uint8_t)(over ? 1 : 0);
+}
+
+// One EXPERIENCE RECORD per env transition: everything SimpleCollector.OnStateTransition (internal/experience/
+// collector.go:30-98) puts into the experiencepb.Experience of every player that acted, in compact form -
+// bit-planes and u16 armies instead of 2 x P x [9][H][W] float tensors (3.7 KB instead of 115 KB at 20x20 4P): what a
+// rank ships over xGMI to the process that feeds StreamAggregator, which expands it (experience.decode_records).
+//   dword 0 currState.Turn | 1 W | H<<8 | P<<16 | flags<<24 (1 done = currState.IsGameOver, 2 fog of war, 4 valid: the env
+//   was not re-dealt) | 2 acted bits (players that submitted an action, collector.go:33-37) | 3 env id
+//   4.. action index per player (Serializer.ActionToIndex, serializer.go:179-198; -1: none) | rewards f32 per player
+//   planes [fd]: prev own[MAXP], prev vis[MAXP], next own[MAXP], next vis[MAXP], general, city, mountain
+//   GenerateActionMask(prev) [MAXP][4][fd] | prev armies u16 [NSLOT*64] | next armies u16 [NSLOT*64]
+template <int MAXP, int NSLOT>
+struct RecordLayout {
+  int fd;
+  __host__ __device__ int action() const { return 4; }
+  __host__ __device__ int reward() const { return 4 + MAXP; }
+  __host__ __device__ int planes() const { return 4 + 2 * MAXP; }
+  __host__ __device__ int mask() const { return planes() + (4 * MAXP + 3) * fd; }
+  __host__ __device__ int army_prev() const { return mask() + 4 * MAXP * fd; }
+  __host__ __device__ int army_next() const { return army_prev() + NSLOT * 32; }
+  __host__ __device__ int total() const { return (army_next() + NSLOT * 32 + 3) / 4 * 4; }
+};
+
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void experience_record_kernel(ExperienceArgs A) {
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.num_envs) return;
+  const int env = A.env_begin + i;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  const uint32_t* sn = A.snap + (size_t)env * A.snap_dw;
+  const SnapLayout<MAXP, NSLOT> S{A.fd};
+  const RecordLayout<MAXP, NSLOT> R{A.fd};
+  uint32_t* rec = A.records + (size_t)i * A.record_dw;
+  bool over, comparable;
+  const float rv = compute_rewards<MAXP, NSLOT>(b, sn, A.fd, over, comparable);
+  // lane p: player p's action -> Serializer.ActionToIndex(action, prevState.Board.W)
+  uint32_t alo = 0u, ahi = 0u;
+  if (lane < A.pstride) {
+    const uint2 w = reinterpret_cast<const uint2*>(A.actions)[(size_t)env * A.pstride + lane];
+    alo = w.x;
+    ahi = w.y;
+  }
+  const int prev_w = (int)(rdlane((lane < 2 * MAXP + 2) ? sn[S.tail() + lane] : 0u, 2 * MAXP + 1) & 0xFFu);
+  const int fx = (int)(int8_t)(alo & 0xFFu), fy = (int)(int8_t)((alo >> 8) & 0xFFu);
+  const int dx = (int)(int8_t)((alo >> 16) & 0xFFu) - fx, dy = (int)(int8_t)(alo >> 24) - fy;
+  int dir = 0;                                   // :183-195: up 0 (and anything that is not a unit step), down 1, left 2, right 3
+  dir = (dx == 0 && dy == 1) ? 1 : dir;
+  dir = (dx == -1 && dy == 0) ? 2 : dir;
+  dir = (dx == 1 && dy == 0) ? 3 : dir;
+  const bool acted = lane < b.P && (ahi & GVEC_ACT_VALID) != 0u;
+  const int aidx = acted ? ((fy * prev_w + fx) * 4 + dir) : -1;
+  const uint32_t acted_bits = (uint32_t)__builtin_amdgcn_ballot_w64(acted);
+  if (lane < MAXP) {
+    rec[R.action() + lane] = (uint32_t)aidx;
+    rec[R.reward() + lane] = __float_as_uint(rv);
+  }
+  if (lane == 0) {
+    rec[0] = (uint32_t)b.turn;
+    rec[1] = (uint32_t)b.W | ((uint32_t)b.H << 8) | ((uint32_t)b.P << 16) |
+             (((over ? 1u : 0u) | ((b.hflags & HF_FOG) ? 2u : 0u) | (comparable ? 4u : 0u)) << 24);
+    rec[2] = acted_bits;
+    rec[3] = (uint32_t)(A.env_id_base + env);
+  }
+  if (lane < A.fd) {
+    uint32_t* pl = rec + R.planes() + lane;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      pl[p * A.fd] = sn[S.own() + p * A.fd + lane];
+      pl[(MAXP + p) * A.fd] = sn[S.vis() + p * A.fd + lane];
+      pl[(2 * MAXP + p) * A.fd] = b.own[p];
+      pl[(3 * MAXP + p) * A.fd] = b.vis[p];
+    }
+    pl[(4 * MAXP + 0) * A.fd] = b.gen;
+    pl[(4 * MAXP + 1) * A.fd] = b.city;
+    pl[(4 * MAXP + 2) * A.fd] = b.mtn;
+  }
+  for (int k = lane; k < 4 * MAXP * A.fd; k += 64) rec[R.mask() + k] = sn[S.mask() + k];
+  for (int k = lane; k < NSLOT * 32; k += 64) rec[R.army_prev() + k] = sn[S.army() + k];
+  store_army_sat16<NSLOT>(b.army, rec + R.army_next());
+  for (int k = R.army_next() + NSLOT * 32 + lane; k < A.record_dw; k += 64) rec[k] = 0u;
 }
 
 // Serializer.StateToTensor (internal/experience/serializer.go:37-109): [9][H][W] float32 from one
@@ -1014,6 +1147,21 @@ hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t
     hipLaunchKernelGGL((rewards_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
                        0, s, a);
     return hipGetLastError();
+  });
+}
+hipError_t launch_experience_records(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((experience_record_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs),
+                       dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    return hipGetLastError();
+  });
+}
+void experience_layout(const Variant& v, int fd, int* snap_dw, int* record_dw) {
+  (void)dispatch(v, [&](auto P_, auto S_) {
+    constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
+    *snap_dw = SnapLayout<P, S>{fd}.total();
+    *record_dw = RecordLayout<P, S>{fd}.total();
+    return hipSuccess;
   });
 }
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {

@@ -118,12 +118,18 @@ struct ExperienceArgs {
   const uint32_t* rows;
   const uint32_t* army16;
   const int32_t* army32;
-  uint32_t* snap;     // [B][snap_dw]: prev own planes, territory[MAXP], armies[MAXP], turn, W|H<<8
-  float* rewards;     // [B][pstride]
-  uint8_t* done;      // [B] or null
+  uint32_t* snap;     // [B][snap_dw]: see SnapLayout (gvec_kernels.hip); indexed by env
+  float* rewards;     // [n][pstride]
+  uint8_t* done;      // [n] or null
   float* obs;         // observe: [B][9*stride] (one player) or [B][pstride][9*stride] (player = -1)
-  int32_t num_envs, fd, row_dw, snap_dw, pstride, stride, player;
+  uint32_t* records;  // experience records [n][record_dw] (RecordLayout)
+  const gvec_action* actions;  // [B][pstride]: what was played in the step between snapshot and record
+  int32_t env_begin;  // snapshot / rewards / records work on envs [env_begin, env_begin + num_envs)
+  int32_t num_envs, fd, row_dw, snap_dw, record_dw, pstride, stride, player, env_id_base;
 };
+hipError_t launch_experience_records(const Variant& v, const ExperienceArgs& a, hipStream_t s);
+// dwords of one env's snapshot / experience record for this variant
+void experience_layout(const Variant& v, int fd, int* snap_dw, int* record_dw);
 hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s);

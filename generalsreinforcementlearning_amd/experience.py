@@ -41,6 +41,134 @@ def index_to_action(index, width, height):
     return fx, fy, tx, ty
 
 
+# --------------------------------------------------------------------------------------------------
+# experience records: the compact per-transition form a rank ships to the StreamAggregator side
+# (include/generals_vec.h "experience records").  decode_records is the consumer: it expands a slab of
+# records into the same batch VecExperienceCollector.after_step yields from the device tensors.
+# --------------------------------------------------------------------------------------------------
+def record_offsets(layout):
+    """Dword offsets of the record fields for a layout dict (VecEngine.experience_record_layout)."""
+    mp, fd, ns = layout["mp"], layout["fd"], layout["ns"]
+    planes = 4 + 2 * mp
+    mask = planes + (4 * mp + 3) * fd
+    army_prev = mask + 4 * mp * fd
+    return {"action": 4, "reward": 4 + mp, "planes": planes, "mask": mask, "army_prev": army_prev, "army_next": army_prev + ns * 32}
+
+
+def _bits(words, n):
+    """[..., fd] uint32 -> [..., n] bool (bit t of the string = bit t & 31 of dword t >> 5)."""
+    b = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=-1, bitorder="little")
+    return b[..., :n].astype(bool)
+
+
+def state_to_tensor(owner_planes, vis_plane, gen, city, mtn, army, player, fog, w, h):
+    """Serializer.StateToTensor (internal/experience/serializer.go:37-109) from bit-planes: owner_planes [P][N] bool,
+    vis_plane / gen / city / mtn [N] bool, army [N] (any integer type; values >= 1000 all normalise to 1) -> float32 [9][h][w]."""
+    n = w * h
+    out = np.zeros((9, n), np.float32)
+    visible = np.ones(n, bool) if not fog else vis_plane                                   # :50
+    out[7] = visible                                                                        # :53-55
+    out[8] = ~visible                                                                       # :58-65
+    open_ = visible & ~mtn                                                                  # mountains short-circuit :68-71
+    out[6] = visible & mtn
+    out[5] = open_ & (gen | city)                                                           # :74-76
+    mine = owner_planes[player]
+    owned = owner_planes.any(0)
+    norm = np.minimum(army.astype(np.float32) / np.float32(1000.0), np.float32(1.0))        # :82-85 float32 division, clamp
+    arm = np.where(army > 0, norm, np.float32(0.0)).astype(np.float32)
+    out[0] = np.where(open_ & mine, arm, 0.0)                                               # :79-89
+    out[2] = open_ & mine
+    out[1] = np.where(open_ & ~mine & owned, arm, 0.0)                                      # :90-100
+    out[3] = open_ & ~mine & owned
+    out[4] = open_ & ~owned                                                                 # :101-104
+    return out.reshape(9, h, w)
+
+
+def decode_records(slab, layout, drop_invalid=False):
+    """slab: uint8 / uint32 array holding k records back to back (host memory).  Returns the batch dict of
+    VecExperienceCollector.after_step (one entry per (record, player) that acted, record-major), plus
+    "env" = the record's env id and "valid" (False: the env was re-dealt since the snapshot, its transition is void)."""
+    rd = layout["record_dw"]
+    recs = np.ascontiguousarray(slab).view(np.uint32).reshape(-1, rd)
+    off, mp, fd = record_offsets(layout), layout["mp"], layout["fd"]
+    out = {k: [] for k in ("env", "player_id", "turn", "width", "height", "state", "next_state", "action", "reward", "done",
+                           "action_mask", "valid")}
+    for r in recs:
+        w, h, P, flags = int(r[1] & 0xFF), int((r[1] >> 8) & 0xFF), int((r[1] >> 16) & 0xFF), int(r[1] >> 24)
+        n = w * h
+        valid = bool(flags & 4)
+        if drop_invalid and not valid:
+            continue
+        acted = int(r[2])
+        if not acted:
+            continue
+        planes = _bits(r[off["planes"]: off["planes"] + (4 * mp + 3) * fd].reshape(4 * mp + 3, fd), n)
+        prev_own, prev_vis, next_own, next_vis = planes[0:mp], planes[mp:2 * mp], planes[2 * mp:3 * mp], planes[3 * mp:4 * mp]
+        gen, city, mtn = planes[4 * mp], planes[4 * mp + 1], planes[4 * mp + 2]
+        masks = _bits(r[off["mask"]: off["mask"] + 4 * mp * fd].reshape(mp, 4, fd), n)              # [p][d][t]
+        army_prev = r[off["army_prev"]: off["army_prev"] + layout["ns"] * 32].view(np.uint16)[:n]
+        army_next = r[off["army_next"]: off["army_next"] + layout["ns"] * 32].view(np.uint16)[:n]
+        actions = r[off["action"]: off["action"] + mp].view(np.int32)
+        rewards = r[off["reward"]: off["reward"] + mp].view(np.float32)
+        for p in range(P):
+            if not (acted >> p) & 1:
+                continue
+            out["env"].append(int(r[3]))
+            out["player_id"].append(p)
+            out["turn"].append(int(r[0].view(np.int32)))
+            out["width"].append(w)
+            out["height"].append(h)
+            out["state"].append(state_to_tensor(prev_own[:P], prev_vis[p], gen, city, mtn, army_prev, p, bool(flags & 2), w, h))
+            out["next_state"].append(state_to_tensor(next_own[:P], next_vis[p], gen, city, mtn, army_next, p, bool(flags & 2), w, h))
+            out["action"].append(int(actions[p]))
+            out["reward"].append(rewards[p])
+            out["done"].append(bool(flags & 1))
+            out["action_mask"].append(np.moveaxis(masks[p], 0, 1).reshape(n * 4))                    # index t*4 + d
+            out["valid"].append(valid)
+    res = {"env": np.array(out["env"], np.int64), "player_id": np.array(out["player_id"], np.int32),
+           "turn": np.array(out["turn"], np.int32), "width": np.array(out["width"], np.int64), "height": np.array(out["height"], np.int64),
+           "action": np.array(out["action"], np.int32), "reward": np.array(out["reward"], np.float32),
+           "done": np.array(out["done"], bool), "valid": np.array(out["valid"], bool),
+           "state": out["state"], "next_state": out["next_state"], "action_mask": out["action_mask"]}
+    if len(res["env"]) and (res["width"] == res["width"][0]).all() and (res["height"] == res["height"][0]).all():
+        for k in ("state", "next_state", "action_mask"):
+            res[k] = np.stack(res[k])
+    return res
+
+
+class ExperienceBatcher:
+    """BatchProcessor (internal/grpc/gameserver/batch_processor.go:12-166) as StreamAggregator configures it
+    (stream_aggregator.go:64-69: 32 experiences or 100 ms, whichever comes first): add() returns the batches that
+    became full, poll(now) flushes a non-empty partial batch whose timeout has passed, flush() forces it
+    (Flush, :71-78).  Single-threaded and clock-injected: the caller owns the loop (the Go version owns goroutines)."""
+
+    def __init__(self, batch_size=32, batch_timeout_s=0.1, clock=None):
+        import time
+        self.batch_size = 32 if batch_size <= 0 else int(batch_size)           # NewBatchProcessor :33-35
+        self.batch_timeout_s = 0.1 if batch_timeout_s <= 0 else float(batch_timeout_s)   # :36-38
+        self.clock = clock or time.monotonic
+        self.current, self.last_flush = [], self.clock()
+
+    def add(self, experiences):
+        out = []
+        for e in experiences:
+            self.current.append(e)
+            if len(self.current) >= self.batch_size:                             # :99-107: full -> flush, ticker reset
+                out.append(self.flush())
+        return out
+
+    def poll(self, now=None):
+        now = self.clock() if now is None else now
+        if self.current and now - self.last_flush >= self.batch_timeout_s:      # ticker :109-118
+            return [self.flush(now)]
+        return []
+
+    def flush(self, now=None):
+        batch, self.current = self.current, []
+        self.last_flush = self.clock() if now is None else now
+        return batch
+
+
 class VecExperienceCollector:
     """Usage per turn:  c.before_step(); err = engine.step(actions); batch = c.after_step(actions)"""
 

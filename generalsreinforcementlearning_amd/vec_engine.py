@@ -212,6 +212,29 @@ class VecEngine:
         """TurnProcessor.captureStateForExperience (turn_processor.go:116-121): snapshot before the step."""
         check(self.L.gvec_experience_begin(self.h), "gvec_experience_begin")
 
+    def experience_begin_range(self, env_begin, n):
+        check(self.L.gvec_experience_begin_range(self.h, env_begin, n), "gvec_experience_begin_range")
+
+    def experience_record_layout(self):
+        """dict(record_dw, mp, fd, ns, max_players, stride): how to parse gvec_experience_records' output."""
+        out = (C.c_int32 * 8)()
+        check(self.L.gvec_experience_record_layout(self.h, out), "gvec_experience_record_layout")
+        return {"record_dw": out[0], "mp": out[1], "fd": out[2], "ns": out[3], "max_players": out[4], "stride": out[5]}
+
+    def experience_record_bytes(self):
+        return check(self.L.gvec_experience_record_bytes(self.h), "gvec_experience_record_bytes")
+
+    def experience_records(self, dst_device_ptr, actions=None, env_begin=0, n=None, env_id_base=0):
+        """Writes the compact experience records of envs [env_begin, env_begin+n) to device memory.
+        actions: the [B][max_players] array that was stepped (host numpy), or None = the handle's action buffer."""
+        n = self.B - env_begin if n is None else n
+        a = None if actions is None else np.ascontiguousarray(actions, ACTION_DTYPE).reshape(self.B, self.max_p)
+        check(self.L.gvec_experience_records(self.h, _ptr(a), MEM_HOST, env_begin, n, env_id_base, C.c_void_p(int(dst_device_ptr))),
+              "gvec_experience_records")
+
+    def record_agent_actions(self, on=True):
+        check(self.L.gvec_record_agent_actions(self.h, int(bool(on))), "gvec_record_agent_actions")
+
     def experience_rewards(self):
         """CalculateReward(prev snapshot, current, player) -> (rewards[B][P] float32, done[B] bool)."""
         r = np.zeros((self.B, self.max_p), np.float32)

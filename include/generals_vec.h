@@ -263,7 +263,37 @@ int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permil
  *                           semantics (board owner, army >= 2, no Alive check) and
  *                           direction order 0 up, 1 down, 2 left, 3 right. */
 int32_t gvec_experience_begin(gvec_handle* h);
+/* The same snapshot for envs [env_begin, env_begin+n) only (a consumer that samples a slice of the batch). */
+int32_t gvec_experience_begin_range(gvec_handle* h, int32_t env_begin, int32_t n);
 int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, int32_t mem);
+
+/* ---- experience records: what a rank ships to the process feeding StreamAggregator ----
+ * One compact record per env transition = everything SimpleCollector.OnStateTransition
+ * (internal/experience/collector.go:30-98) puts into the experiencepb.Experience of every player that
+ * acted, with the two [9][H][W] float tensors per player replaced by what they are functions of:
+ *   dword 0 currState.Turn | 1 W | H<<8 | P<<16 | flags<<24 (1 done = currState.IsGameOver, 2 fog of war,
+ *   4 valid: the env was stepped, not re-dealt, since the snapshot) | 2 acted bits (bit p: player p
+ *   submitted an action) | 3 env id (env_id_base + env) |
+ *   action[MP] int32 (Serializer.ActionToIndex on prevState.Board.W, serializer.go:179-198; -1 none) |
+ *   reward[MP] float32 (CalculateReward, rewards.go:40-85) |
+ *   bit-planes of fd dwords (bit t = tile y*W+x): prev own[MP], prev visible[MP], next own[MP],
+ *   next visible[MP], general, city, mountain |
+ *   Serializer.GenerateActionMask(prevState, p) as [MP][4][fd] direction planes (0 up, 1 down, 2 left, 3 right) |
+ *   prev armies, next armies: uint16[NS*64], tile t at halfword t, saturated to [0, 65535] - exact for
+ *   StateToTensor, which clamps army/1000 at 1 (serializer.go:82-85).
+ * MP / fd / NS come from gvec_experience_record_layout: out8 = {dwords per record, MP, fd, NS, max_players,
+ * tile_stride, 0, 0}.  3,660 bytes at 20x20 4P instead of 115 KB of tensors; the consumer expands
+ * (generalsreinforcementlearning_amd/experience.py: decode_records).
+ * gvec_experience_records needs the snapshot of gvec_experience_begin[_range] taken BEFORE the step and the
+ * actions[B][max_players] that were played (NULL = the handle's action buffer: the last host-mode
+ * gvec_step, or the device agent's moves when gvec_record_agent_actions is on); it writes n records to
+ * dst_device on the handle's stream. */
+int32_t gvec_experience_record_layout(gvec_handle* h, int32_t* out8);
+int32_t gvec_experience_record_bytes(gvec_handle* h);
+int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int32_t mem, int32_t env_begin,
+                                int32_t n, int32_t env_id_base, void* dst_device);
+/* on != 0: per-turn rollouts (gvec_rollout fused = 0) store the agent's moves in the handle's action buffer. */
+int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on);
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
 
