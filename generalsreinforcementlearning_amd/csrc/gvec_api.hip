@@ -50,6 +50,7 @@ struct gvec_handle {
   uint32_t* d_snap = nullptr;                // experience snapshots [B][snap_dw] (allocated on first use)
   int snap_dw = 0, record_dw = 0;
   bool record_actions = false;               // per-turn rollouts write the agent's moves into d_actions
+  int32_t* d_gym_prev = nullptr;             // [B][3*MAXP] player stats as of the previous gvec_gym_observe
   uint32_t* p_hdr = nullptr;
   uint32_t* p_rows = nullptr;
   uint32_t* p_army16 = nullptr;
@@ -355,7 +356,7 @@ int32_t gvec_destroy(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_zeros, h->d_counters,
-                  h->d_snap, h->p_hdr, h->p_rows, h->p_army16, h->p_army32};
+                  h->d_snap, h->d_gym_prev, h->p_hdr, h->p_rows, h->p_army16, h->p_army32};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : h->stage_ptr)
@@ -826,6 +827,59 @@ int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int3
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
   if (!h) return GVEC_E_INVALID;
   h->record_actions = on != 0;
+  return GVEC_OK;
+}
+
+int32_t gvec_gym_observe(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask,
+                         double* reward, uint8_t* done, int8_t* winner) {
+  if (!h || !turn_count || !obs || !mask || player < 0 || player >= h->maxp || max_turns < 1) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->d_gym_prev) {
+    HIPCHK(hipMalloc(&h->d_gym_prev, (size_t)h->cfg.num_envs * 3 * h->var.maxp * 4));
+    HIPCHK(hipMemsetAsync(h->d_gym_prev, 0, (size_t)h->cfg.num_envs * 3 * h->var.maxp * 4, h->stream));
+  }
+  GymArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
+  a.turn_count = turn_count;
+  a.obs = obs;
+  a.mask = mask;
+  a.reward = reward;
+  a.done = done;
+  a.winner = winner;
+  a.prev_stats = h->d_gym_prev;
+  a.num_envs = h->cfg.num_envs;
+  a.fd = h->fd;
+  a.row_dw = h->row_dw;
+  a.stride = h->stride;
+  a.player = player;
+  a.max_turns = max_turns;
+  HIPCHK(launch_gym_observe(h->var, a, h->stream));
+  return GVEC_OK;
+}
+
+int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_actions, const uint8_t* mask, const uint8_t* resetting,
+                         gvec_action* actions, uint8_t* played, uint8_t* invalid, uint8_t* error) {
+  if (!h || !gym_actions || !mask || !actions || player < 0 || player >= h->maxp) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  GymActArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.gym_actions = gym_actions;
+  a.mask = mask;
+  a.resetting = resetting;
+  a.actions = actions;
+  a.played = played;
+  a.invalid = invalid;
+  a.error = error;
+  a.num_envs = h->cfg.num_envs;
+  a.stride = h->stride;
+  a.pstride = h->maxp;
+  a.player = player;
+  HIPCHK(launch_gym_actions(a, h->stream));
   return GVEC_OK;
 }
 

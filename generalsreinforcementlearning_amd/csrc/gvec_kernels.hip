@@ -602,6 +602,155 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
 }
 
 // =========================================================================================
+// python/generals_gym/generals_env.py on the device: what GeneralsEnv builds from the GameState proto the
+// server sends for its player token - observation (:291-342), valid-action mask (:344-387), reward
+// (:499-561) - computed straight from the resident state with the proto's fog rules applied in the kernel
+// (internal/grpc/gameserver/server.go:556-582: a tile that is neither visible nor "known in fog" shows type
+// NORMAL / owner -1 / army 0; a fogged tile keeps its type, hides owner and army.  A hidden tile is a normal
+// tile by definition (visibility_optimized.go:189-191), so the shown type is always the real one).
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymArgs A) {
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  const bool fog_on = (b.hflags & HF_FOG) != 0u;
+  uint32_t own_p = 0u, vis_p = 0u, own_any = 0u, lst_cnt[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    own_p = (p == A.player) ? b.own[p] : own_p;
+    vis_p = (p == A.player) ? b.vis[p] : vis_p;
+    own_any |= b.own[p];
+    lst_cnt[p] = (uint32_t)b.count(b.lst[p]);  // PlayerState.tile_count = len(OwnedTiles) (server.go:536)
+  }
+  const uint32_t seen = fog_on ? vis_p : b.valid;  // ComputePlayerVisibility (visibility_optimized.go:166-195)
+  // _get_valid_actions_mask: a tile the proto shows as ours (visible, owner == player) with army > 1, towards a
+  // neighbour on the board whose shown type is not MOUNTAIN; index tile*5 + {up, right, down, left}, +4 = half move
+  const uint32_t src = own_p & seen & b.gt1;
+  const uint32_t m0 = src & b.ok[0], m1 = src & b.ok[1], m2 = src & b.ok[2], m3 = src & b.ok[3], many = m0 | m1 | m2 | m3;
+  float* obs = A.obs + (size_t)env * 9 * (size_t)A.stride;
+  uint8_t* mask = A.mask + (size_t)env * 5 * (size_t)A.stride;
+  // channel 7: min(turn_count / max_turns, 1.0) in float64, stored as float32 (:338-339)
+  double tcn = (double)A.turn_count[env] / (double)A.max_turns;
+  tcn = tcn < 1.0 ? tcn : 1.0;
+  const float tc = (float)tcn;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int t = 64 * s + lane;
+    const bool vis = b.gather(seen, s) != 0u, mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u;
+    const bool g = b.gather(b.gen, s) != 0u, c = b.gather(b.city, s) != 0u, mt = b.gather(b.mtn, s) != 0u;
+    const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
+    const int32_t army = vis ? b.army[s] : 0;                                    // hidden and fogged tiles: army 0
+    // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
+    const float la = (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
+    if (t < A.stride) {
+      const bool in = t < b.N;
+      const size_t n = (size_t)A.stride;
+      obs[0 * n + t] = (in && vis) ? 1.0f : 0.0f;                                // :312-314
+      obs[1 * n + t] = (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f);   // :316-322 (owner -1 unless visible)
+      obs[2 * n + t] = in ? la : 0.0f;
+      obs[3 * n + t] = (in && !g && !c && !mt) ? 1.0f : 0.0f;                    // :328-336 one-hot type
+      obs[4 * n + t] = (in && mt) ? 1.0f : 0.0f;
+      obs[5 * n + t] = (in && c) ? 1.0f : 0.0f;
+      obs[6 * n + t] = (in && g) ? 1.0f : 0.0f;
+      obs[7 * n + t] = tc;                                                       // the whole plane, like obs[7, :, :] = ...
+      obs[8 * n + t] = 0.0f;                                                     // left zero by the reference (:341-343)
+      uint8_t* mk = mask + (size_t)t * 5;
+      mk[0] = (uint8_t)k0;
+      mk[1] = (uint8_t)k1;
+      mk[2] = (uint8_t)k2;
+      mk[3] = (uint8_t)k3;
+      mk[4] = (uint8_t)k4;
+    }
+  }
+  // _calculate_reward (:499-561) against the stats this kernel stored at its previous call, then store the new ones
+  const int na = __builtin_popcount(b.alive);
+  const bool over = (b.hflags & HF_DONE) != 0u;
+  const int winner = (over && b.P > 1 && na == 1) ? (31 - __builtin_clz(b.alive)) : -1;   // Engine.GetWinner
+  int32_t* prev = A.prev_stats + (size_t)env * 3 * MAXP;
+  if (lane == 0) {
+    double r = 0.0;
+    const int pl = A.player;
+    int32_t cur_tc = 0, cur_ac = 0;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      cur_tc = (p == pl) ? (int32_t)lst_cnt[p] : cur_tc;
+      cur_ac = (p == pl) ? (int32_t)b.hdr_get(H_ARMYCNT + p) : cur_ac;
+    }
+    r += (double)(cur_tc - prev[pl]) * 1.0;                                       // :540-542
+    r += (double)(cur_ac - prev[MAXP + pl]) * 0.01;                               // :544-546
+    for (int q = 0; q < b.P; ++q)                                                 // :548-555
+      if (q != pl && prev[2 * MAXP + q] != 0 && !((b.alive >> q) & 1u)) r += 50.0;
+    if (over) r = (winner == pl) ? 100.0 : -100.0;                                // :520-524
+    if (A.reward) A.reward[env] = r;
+    if (A.done) A.done[env] = (uint8_t)(over ? 1 : 0);
+    if (A.winner) A.winner[env] = (int8_t)winner;
+  }
+  // lanes H_ARMYCNT + p of the header register hold ArmyCount[p]: fetched by every lane (a cross-lane read must
+  // not sit under a divergent branch: masked-off source lanes read as 0)
+  const uint32_t ac = bperm((H_ARMYCNT + (lane & (MAXP - 1))) << 2, b.hv);
+  if (lane < MAXP) {
+    uint32_t tcl = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) tcl = (lane == p) ? lst_cnt[p] : tcl;
+    prev[lane] = (int32_t)tcl;
+    prev[MAXP + lane] = (int32_t)ac;
+    prev[2 * MAXP + lane] = (int32_t)((b.alive >> lane) & 1u);
+  }
+}
+
+// GeneralsEnv.step's action handling for player `player` of every env (one thread per env):
+// :226-241 an action the mask rejects is not submitted (the env sits the call out: GVEC_ACT_SKIP_ENV);
+// _action_index_to_game_action :389-441 (a half move, index 4, takes the FIRST of up / right / down / left whose
+// target is on the board - mountains are not checked there); the server then validates the move it received
+// (action_validator.go:114-139): a half move whose first in-board direction is illegal is refused.
+// `resetting` envs are re-dealt in this step (GVEC_ACT_RESET_ENV) whatever the action.
+__global__ void gym_actions_kernel(GymActArgs A) {
+  const int env = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (env >= A.num_envs) return;
+  const uint32_t dims = A.hdr[(size_t)env * HDR_DW + H_DIMS];
+  const int w = (int)(dims & 0xFFu), h = (int)((dims >> 8) & 0xFFu);
+  const long long a = A.gym_actions[env];
+  const long long n5 = 5ll * A.stride;
+  const uint8_t* mask = A.mask + (size_t)env * 5 * (size_t)A.stride;
+  const bool in_range = a >= 0 && a < n5;
+  const bool valid = in_range && mask[a] != 0;
+  const int from = in_range ? (int)(a / 5) : 0, info = in_range ? (int)(a % 5) : 0;
+  const int fx = from % w, fy = from / w;   // tile index with the env's own width (from < stride; a tile beyond the board has no mask bit)
+  const bool half = info == 4;
+  int d = half ? 3 : info;
+  if (half) {
+    if (fx - 1 >= 0) d = 3;
+    if (fy + 1 < h) d = 2;
+    if (fx + 1 < w) d = 1;
+    if (fy - 1 >= 0) d = 0;
+  }
+  const bool accepted = valid && mask[(size_t)from * 5 + d] != 0;
+  const bool resetting = A.resetting && A.resetting[env] != 0;
+  const bool played = accepted || resetting;
+  const int dx = (d == 1) - (d == 3), dy = (d == 2) - (d == 0);
+  gvec_action* acts = A.actions + (size_t)env * A.pstride;
+  gvec_action mine;
+  mine.from_x = (int8_t)fx;
+  mine.from_y = (int8_t)fy;
+  mine.to_x = (int8_t)(fx + dx);
+  mine.to_y = (int8_t)(fy + dy);
+  mine.flags = (uint8_t)(played ? (GVEC_ACT_VALID | (half ? GVEC_ACT_HALF : 0u)) : 0u);
+  mine.reserved[0] = mine.reserved[1] = mine.reserved[2] = 0;
+  acts[A.player] = mine;
+  uint8_t f0 = acts[0].flags & (uint8_t)~(GVEC_ACT_SKIP_ENV | GVEC_ACT_RESET_ENV);
+  if (!played) f0 |= GVEC_ACT_SKIP_ENV;
+  if (resetting) f0 |= GVEC_ACT_RESET_ENV;
+  acts[0].flags = f0;
+  if (A.played) A.played[env] = (uint8_t)played;
+  if (A.invalid) A.invalid[env] = (uint8_t)(!valid && !resetting);
+  if (A.error) A.error[env] = (uint8_t)(valid && !accepted && !resetting);
+}
+
+// =========================================================================================
 // import: planes -> resident record (gvec_reset / gvec_write_state / pool build)
 // =========================================================================================
 template <int MAXP, int NSLOT>
@@ -1163,6 +1312,17 @@ void experience_layout(const Variant& v, int fd, int* snap_dw, int* record_dw) {
     *record_dw = RecordLayout<P, S>{fd}.total();
     return hipSuccess;
   });
+}
+hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((gym_observe_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
+                       0, s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gym_actions_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
   return dispatch(v, [&](auto P_, auto S_) {

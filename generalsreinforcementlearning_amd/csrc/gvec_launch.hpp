@@ -130,6 +130,34 @@ struct ExperienceArgs {
 hipError_t launch_experience_records(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 // dwords of one env's snapshot / experience record for this variant
 void experience_layout(const Variant& v, int fd, int* snap_dw, int* record_dw);
+// python/generals_gym on the device
+struct GymArgs {
+  const uint32_t* hdr;
+  const uint32_t* rows;
+  const uint32_t* army16;
+  const int32_t* army32;
+  const int64_t* turn_count;  // [B] GeneralsEnv.turn_count
+  float* obs;                 // [B][9][stride]
+  uint8_t* mask;              // [B][stride*5]
+  double* reward;             // [B] or null
+  uint8_t* done;              // [B] or null
+  int8_t* winner;             // [B] or null
+  int32_t* prev_stats;        // [B][3*MAXP]: tile_count, army_count, alive as of the previous call (read, then rewritten)
+  int32_t num_envs, fd, row_dw, stride, player, max_turns;
+};
+struct GymActArgs {
+  const uint32_t* hdr;
+  const int64_t* gym_actions;  // [B] indices into Discrete(board_size * 5)
+  const uint8_t* mask;         // [B][stride*5] of the last gym_observe
+  const uint8_t* resetting;    // [B] or null
+  gvec_action* actions;        // [B][pstride] in / out
+  uint8_t* played;             // [B] outputs, any may be null
+  uint8_t* invalid;
+  uint8_t* error;
+  int32_t num_envs, stride, pstride, player;
+};
+hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s);
+hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s);
 hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_rewards(const Variant& v, const ExperienceArgs& a, hipStream_t s);
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s);

@@ -24,6 +24,9 @@ because a vector env cannot wait for a per-env reset() call.
 import numpy as np
 
 from .vec_engine import ACT_HALF, ACT_SKIP_ENV, ACT_VALID, ACTION_DTYPE, VecEngine
+from ._lib import check
+
+ACT_RESET_ENV = 8  # include/generals_vec.h GVEC_ACT_RESET_ENV
 
 # proto/common/v1/common.proto TileType as used by generals_env.py:322-329
 _DIRS = ((0, -1), (1, 0), (0, 1), (-1, 0))  # up, right, down, left (generals_env.py:369, 413)
@@ -132,7 +135,10 @@ class GeneralsVecEnv:
     reset() -> (obs, info);  step(actions[B]) -> (obs, reward, terminated, truncated, info)."""
 
     def __init__(self, num_envs, board_width=15, board_height=15, max_players=2, fog_of_war=True, max_turns=500,
-                 seed=0, device=0, board_pool=1024):
+                 seed=0, device=0, board_pool=1024, device_outputs=False):
+        """device_outputs=True: observation / mask / reward / flags are torch tensors on the GPU, produced by the
+        gym kernels (gvec_gym_observe / gvec_gym_actions), and `step` takes a CUDA int64 tensor of actions: no
+        board state crosses PCIe.  False (default): numpy arrays built on the host from a state read-back."""
         self.num_envs = num_envs
         self.board_width, self.board_height = board_width, board_height
         self.board_size = board_width * board_height
@@ -153,6 +159,22 @@ class GeneralsVecEnv:
         self.valid_actions_mask = None
         self._obs_bufs = [np.zeros((num_envs, 9, board_height, board_width), np.float32) for _ in range(2)]
         self._obs_flip = 0
+        self.device_outputs = bool(device_outputs)
+        if self.device_outputs:
+            import torch
+            self._t = torch
+            dev = torch.device("cuda", device)
+            self._dev = dev
+            self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            n = self.board_size
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+            self._d_obs = [z((num_envs, 9, board_height, board_width), torch.float32) for _ in range(2)]
+            self._d_mask = [z((num_envs, n * 5), torch.uint8) for _ in range(2)]
+            self._d_reward, self._d_done, self._d_winner = z(num_envs, torch.float64), z(num_envs, torch.uint8), z(num_envs, torch.int8)
+            self._d_turn = z(num_envs, torch.int64)
+            self._d_needs_reset = z(num_envs, torch.uint8)
+            self._d_acts = z((num_envs, max_players, 8), torch.uint8)
+            self._d_played, self._d_invalid, self._d_error = (z(num_envs, torch.uint8) for _ in range(3))
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _read(self):
@@ -171,11 +193,51 @@ class GeneralsVecEnv:
         return obs
 
     # ---- gym API ------------------------------------------------------------------------------------
+    # ---- device mode ------------------------------------------------------------------------------
+    def _gym_observe(self):
+        self._obs_flip ^= 1
+        obs, mask = self._d_obs[self._obs_flip], self._d_mask[self._obs_flip]
+        e = self.engine
+        check(e.L.gvec_gym_observe(e.h, self.player_id, self._d_turn.data_ptr(), self.max_turns, obs.data_ptr(), mask.data_ptr(),
+                                   self._d_reward.data_ptr(), self._d_done.data_ptr(), self._d_winner.data_ptr()), "gvec_gym_observe")
+        self.valid_actions_mask = mask.view(self._t.bool)
+        return obs
+
+    def _reset_device(self):
+        self._d_turn.zero_()
+        self._d_needs_reset.zero_()
+        obs = self._gym_observe()          # also stores the stats the first step's reward is measured against
+        return obs, {"player_id": self.player_id, "valid_actions_mask": self.valid_actions_mask, "turn": self._d_turn.clone()}
+
+    def _step_device(self, actions):
+        t, e = self._t, self.engine
+        actions = t.as_tensor(actions, dtype=t.int64, device=self._dev).reshape(self.num_envs).contiguous()
+        resetting = self._d_needs_reset.clone()
+        # opponents: the on-device random agent writes every slot; the learner's slot is then overwritten
+        check(e.L.gvec_agent_actions(e.h, self._seed + 1000 * self._episode + 1, 0, self._d_acts.data_ptr(), 1), "gvec_agent_actions")
+        self._episode += 1
+        prev_mask = self._d_mask[self._obs_flip]
+        check(e.L.gvec_gym_actions(e.h, self.player_id, actions.data_ptr(), prev_mask.data_ptr(), resetting.data_ptr(), self._d_acts.data_ptr(),
+                                   self._d_played.data_ptr(), self._d_invalid.data_ptr(), self._d_error.data_ptr()), "gvec_gym_actions")
+        e.step_device(self._d_acts.data_ptr())     # aborted turns are the opponents' business, as over gRPC
+        rs, played = resetting.bool(), self._d_played.bool()
+        self._d_turn = t.where(rs, t.zeros_like(self._d_turn), self._d_turn + played.to(t.int64))
+        obs = self._gym_observe()
+        reward = t.where(rs, t.zeros_like(self._d_reward), t.where(played, self._d_reward, t.full_like(self._d_reward, -0.1)))
+        terminated = self._d_done.bool() & played & ~rs
+        truncated = (self._d_turn >= self.max_turns) & played & ~rs
+        self._d_needs_reset = (terminated | truncated).to(t.uint8)
+        info = {"turn": self._d_turn.clone(), "valid_actions_mask": self.valid_actions_mask, "invalid_action": self._d_invalid.bool(),
+                "error": self._d_error.bool(), "winner": t.where(terminated, self._d_winner, t.full_like(self._d_winner, -1)), "reset": rs}
+        return obs, reward, terminated, truncated, info
+
     def reset(self, seed=None):
         if seed is not None:
             self._seed = seed
         self.engine.reset_generated(self._seed * 1000003 + 17)
         self.engine.build_board_pool(self._pool, self._seed * 7919 + 5)
+        if self.device_outputs:
+            return self._reset_device()
         self.turn_count[:] = 0
         self._needs_reset[:] = False
         view, self._stats = self._read()
@@ -184,6 +246,8 @@ class GeneralsVecEnv:
         return obs, info
 
     def step(self, actions):
+        if self.device_outputs:
+            return self._step_device(actions)
         B, W, H = self.num_envs, self.board_width, self.board_height
         actions = np.asarray(actions, np.int64).reshape(B)
         resetting = self._needs_reset.copy()
@@ -194,11 +258,6 @@ class GeneralsVecEnv:
         from_idx = fy * W + fx
         accepted = valid & self.valid_actions_mask[np.arange(B), from_idx * 5 + d]
         played = accepted | resetting
-        # finished / truncated envs: force the engine's done flag so this step re-deals them
-        if resetting.any():
-            done = self.engine.game_state(fields=("done",))["done"]
-            done[resetting] = 1
-            self.engine.write_state({"done": done})
         acts = self.engine.agent_actions(self._seed + 1000 * self._episode + 1)   # opponents (and a draft for player 0)
         self._episode += 1
         a0 = acts[:, self.player_id]
@@ -207,6 +266,8 @@ class GeneralsVecEnv:
         acts[:, self.player_id] = a0
         first = acts[:, 0]
         first["flags"] = np.where(played, first["flags"] & ~np.uint8(ACT_SKIP_ENV), first["flags"] | np.uint8(ACT_SKIP_ENV))
+        # finished / truncated envs are re-dealt in this step (GVEC_ACT_RESET_ENV): no read-back / poke of `done`
+        first["flags"] = np.where(resetting, first["flags"] | np.uint8(ACT_RESET_ENV), first["flags"])
         acts[:, 0] = first
         self.engine.step(acts)  # per-env move errors (aborted turns) are the opponents' business, as over gRPC
         prev = self._stats

@@ -297,6 +297,27 @@ int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on);
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
 
+/* ---- python/generals_gym on the device ------------------------------------------
+ * What GeneralsEnv builds on the client from the GameState proto of its player token, computed straight
+ * from the resident state with the proto's fog rules (server.go:556-582) applied in the kernel.  Every
+ * pointer is a DEVICE pointer (e.g. a torch tensor); work is enqueued on the handle's stream.
+ * gvec_gym_observe: obs [B][9][tile_stride] float32 = GeneralsEnv._get_observation (generals_env.py:291-342:
+ *   visible, ownership 0.5 / 1.0, log(army+1)/10, one-hot type, turn_count/max_turns, zeros), tile index
+ *   y*W + x; mask [B][tile_stride*5] 0/1 bytes = _get_valid_actions_mask (:344-387), index tile*5 + {up, right,
+ *   down, left, half}; reward [B] float64 = _calculate_reward (:499-561) against the player stats stored by
+ *   the PREVIOUS gvec_gym_observe call of this handle (the call after a reset yields a meaningless reward);
+ *   done = Engine.IsGameOver, winner = Engine.GetWinner.  reward / done / winner may be NULL.
+ * gvec_gym_actions: GeneralsEnv.step's action handling (:226-259, :389-441) for `player`: decodes
+ *   gym_actions[B] (indices into Discrete(board_size*5)) against `mask` (the last gvec_gym_observe's), writes
+ *   the player's move into actions[B][max_players] (the other players' slots are kept: fill them first, e.g.
+ *   with gvec_agent_actions), marks an env whose action is refused GVEC_ACT_SKIP_ENV and a `resetting` env
+ *   GVEC_ACT_RESET_ENV; played / invalid / error [B] 0/1 outputs (any may be NULL). */
+int32_t gvec_gym_observe(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns,
+                         float* obs, uint8_t* mask, double* reward, uint8_t* done, int8_t* winner);
+int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_actions, const uint8_t* mask,
+                         const uint8_t* resetting, gvec_action* actions, uint8_t* played, uint8_t* invalid,
+                         uint8_t* error);
+
 /* ---- experience gather support ---------------------------------------
  * Writes the compact state records of envs [env_begin, env_begin+n) into a device
  * buffer (e.g. a torch tensor handed to RCCL) as a slab [n] headers | [n] plane blocks |

@@ -285,3 +285,73 @@ def test_golden_action_indices_distinct(c):
     from generalsreinforcementlearning_amd.experience import action_to_index
     idx = {int(action_to_index(_one_action(*m), c["w"])[0]) for m in c["moves"]}
     assert len(idx) == c["expect_distinct"]
+
+
+# ---- device mode: the gym kernels (gvec_gym_observe / gvec_gym_actions) ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fog,P", [(True, 2), (True, 4), (False, 3)], ids=["fog_p2", "fog_p4", "nofog_p3"])
+def test_device_vector_env_equals_host_vector_env(fog, P):
+    """device_outputs=True (observation / mask / reward / flags as CUDA tensors from the gym kernels, actions decoded on
+    the device) against the host-numpy mode, which the tests above pin to the scalar restatement of generals_env.py:
+    every output of every step, bit for bit - invalid actions, half moves, terminations, truncations and re-deals included."""
+    import torch
+    kw = dict(board_width=9, board_height=8, max_players=P, fog_of_war=fog, max_turns=30, seed=5, board_pool=64)
+    host = V.GeneralsVecEnv(48, **kw)
+    dev = V.GeneralsVecEnv(48, device_outputs=True, **kw)
+    ho, hi = host.reset()
+    do, di = dev.reset()
+    assert do.is_cuda and do.dtype == torch.float32 and di["valid_actions_mask"].dtype == torch.bool
+    assert np.array_equal(do.cpu().numpy().view(np.uint32), ho.view(np.uint32)) and np.array_equal(di["valid_actions_mask"].cpu().numpy(), hi["valid_actions_mask"])
+    rng = np.random.default_rng(2)
+    seen = {"term": 0, "trunc": 0, "invalid": 0, "error": 0, "half": 0}
+    for k in range(150):
+        mask = hi["valid_actions_mask"]
+        acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in mask])
+        if k % 5 == 2:
+            acts[:6] = [int(np.flatnonzero(~m)[rng.integers(0, 20)]) for m in mask[:6]]      # invalid
+            acts[6] = -3
+            acts[7] = 9 * 8 * 5 + 4                                                          # out of range
+        if k % 3 == 0:                                                                        # half moves (index 4) where legal
+            for e in range(8, 20):
+                hm = np.flatnonzero(mask[e][4::5])
+                if len(hm):
+                    acts[e] = int(hm[rng.integers(0, len(hm))]) * 5 + 4
+                    seen["half"] += 1
+        ho, hr, hterm, htrunc, hi = host.step(acts)
+        do, dr, dterm, dtrunc, di = dev.step(torch.from_numpy(acts).cuda())
+        assert np.array_equal(do.cpu().numpy().view(np.uint32), ho.view(np.uint32)), k
+        assert np.array_equal(di["valid_actions_mask"].cpu().numpy(), hi["valid_actions_mask"]), k
+        assert dr.dtype == torch.float64 and np.array_equal(dr.cpu().numpy().view(np.uint64), np.asarray(hr, np.float64).view(np.uint64)), k
+        assert np.array_equal(dterm.cpu().numpy(), hterm) and np.array_equal(dtrunc.cpu().numpy(), htrunc)
+        for f in ("turn", "invalid_action", "error", "winner", "reset"):
+            assert np.array_equal(di[f].cpu().numpy(), np.asarray(hi[f])), (k, f)
+        seen["term"] += int(hterm.sum()); seen["trunc"] += int(htrunc.sum())
+        seen["invalid"] += int(hi["invalid_action"].sum()); seen["error"] += int(hi["error"].sum())
+    assert seen["trunc"] > 0 and seen["invalid"] > 0 and seen["half"] > 0
+    # the two engines went through identical states
+    H.assert_states_equal(dev.engine.game_state(), host.engine.game_state(), "device vs host vector env")
+    host.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_gym_observation_log_channel_is_numpys_float64_log():
+    """Channel 2 = float32(np.log(army + 1) / 10.0) with the log in float64 (generals_env.py:324-326): checked for
+    every army 1 .. 2^18 and for 2^18 samples up to 2^31 - 2, on a board where every tile is visible (fog off)."""
+    import torch
+    import generalsreinforcementlearning_amd as g
+    from generalsreinforcementlearning_amd._lib import check
+    B, w, h = 256, 32, 32
+    eng = g.VecEngine(B, w, h, 2, fog_of_war=False, stream=torch.cuda.current_stream().cuda_stream)
+    eng.reset_generated(4)
+    st = eng.game_state(fields=("army", "type"))
+    rng = np.random.default_rng(3)
+    for values in (np.arange(1, B * w * h + 1, dtype=np.int64), rng.integers(1, 2 ** 31 - 1, B * w * h, dtype=np.int64)):
+        army = values.astype(np.int32).reshape(B, w * h)
+        eng.write_state({"army": army})
+        obs = torch.zeros((B, 9, w * h), dtype=torch.float32, device="cuda")
+        mask = torch.zeros((B, w * h * 5), dtype=torch.uint8, device="cuda")
+        tc = torch.zeros(B, dtype=torch.int64, device="cuda")
+        check(eng.L.gvec_gym_observe(eng.h, 0, tc.data_ptr(), 10, obs.data_ptr(), mask.data_ptr(), None, None, None), "gvec_gym_observe")
+        got = obs[:, 2].cpu().numpy()
+        want = (np.log(army.astype(np.int64) + 1) / 10.0).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
