@@ -20,6 +20,12 @@
 #pragma once
 #include "gvec_device.hpp"
 
+// Profiling builds only (scripts/profile_phases.sh): -DGVEC_PROFILE_SKIP=<bits> compiles one phase of the turn out
+// so that per-phase instruction counts can be read off the PMC counters.  Never defined in the shipped library.
+#ifndef GVEC_PROFILE_SKIP
+#define GVEC_PROFILE_SKIP 0
+#endif
+
 namespace gvec {
 
 // ---- row-wise cross-lane helpers (a "row" = ROWL consecutive lanes) ---------------------------------
@@ -132,9 +138,16 @@ struct PBoard {
   }
 
   // ---- header (Board's) ---------------------------------------------------------------------------
-  __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
+  // Split in two so that a kernel can put every load of the board in flight BEFORE anything waits for the
+  // header: issue_hdr, load_army_narrow, load_planes, land(), decode_hdr - one memory round trip per board
+  // instead of two (the turn is a latency chain: a second round trip is ~15 % of a wave's life).
+  __device__ __forceinline__ void issue_hdr(const uint32_t* hdr_env) {
     const int lane = lane_id();
     hv = (lane < HDR_DW) ? hdr_env[lane] : 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rowbit[k] = 1u << lane_player(k);
+  }
+  __device__ __forceinline__ void decode_hdr() {
     turn = (int)rdlane(hv, H_TURN);
     const uint32_t dims = rdlane(hv, H_DIMS);
     W = (int)(dims & 0xFFu);
@@ -144,8 +157,34 @@ struct PBoard {
     N = W * H;
     alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
+  }
+  __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
+    issue_hdr(hdr_env);
+    decode_hdr();
+  }
+  // Every register a load of this board writes is "touched" here: the compiler can neither sink those loads below a
+  // later (header-dependent) branch nor split the wait - all of them are in flight together and land at this point.
+  __device__ __forceinline__ void land() {
+    asm volatile("" : "+v"(hv));
 #pragma unroll
-    for (int k = 0; k < NR; ++k) rowbit[k] = 1u << lane_player(k);
+    for (int s = 0; s < NSLOT; ++s) asm volatile("" : "+v"(army[s]));
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      asm volatile("" : "+v"(own[k]));
+      asm volatile("" : "+v"(lst[k]));
+      asm volatile("" : "+v"(vis[k]));
+    }
+    asm volatile("" : "+v"(chg));
+    asm volatile("" : "+v"(vch));
+    asm volatile("" : "+v"(gt1));
+    asm volatile("" : "+v"(gen));
+    asm volatile("" : "+v"(city));
+    asm volatile("" : "+v"(mtn));
+    asm volatile("" : "+v"(valid));
+    asm volatile("" : "+v"(ncol0));
+    asm volatile("" : "+v"(ncolL));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(ok[d]));
   }
   __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
@@ -218,6 +257,10 @@ struct PBoard {
   // narrow (u16 pairs) / wide (int32 escape) army storage: see gvec_device.hpp "army storage"
   __device__ __forceinline__ void load_army(const ArmyCRef& a) {
     army_load_narrow<NSLOT>(army, a.n);
+    if (hflags & HF_WIDE) army_load_wide<NSLOT>(army, a.w);
+  }
+  __device__ __forceinline__ void load_army_narrow(const ArmyCRef& a) { army_load_narrow<NSLOT>(army, a.n); }  // needs no header
+  __device__ __forceinline__ void load_army_wide_if_flagged(const ArmyCRef& a) {
     if (hflags & HF_WIDE) army_load_wide<NSLOT>(army, a.w);
   }
   __device__ __forceinline__ void store_army(const ArmyRef& a) {  // sets / clears HF_WIDE: call BEFORE store_hdr
@@ -566,7 +609,7 @@ struct PBoard {
   __device__ __forceinline__ uint32_t turn_step(const ActVec& av, const StepArgs& A, bool& aborted) {
     aborted = false;
     turn++;  // initializeTurn :124-135
-    update_fog();
+    if (!(GVEC_PROFILE_SKIP & 2)) update_fog();
     chg = 0u;
     vch = 0u;
     uint32_t first_err = 0u, elim_seen = 0u;
@@ -574,7 +617,7 @@ struct PBoard {
     int n_orders = 0;
     // Engine.processActions (engine.go:80-115): PlayerID order == slot order (sort.Slice :39-41)
     const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
-    if (present) {  // a turn where nobody moves touches no army
+    if (present && !(GVEC_PROFILE_SKIP & 4)) {  // a turn where nobody moves touches no army
       army_to_lds();
       act_chain<0>(av, first_err, orders, n_orders, elim_seen);
       army_from_lds();
@@ -587,8 +630,8 @@ struct PBoard {
       aborted = true;
       return first_err;
     }
-    production(A.prod_general, A.prod_city, A.prod_normal, A.interval);  // :60
-    update_stats();                                                       // :65,170-179
+    if (!(GVEC_PROFILE_SKIP & 8)) production(A.prod_general, A.prod_city, A.prod_normal, A.interval);  // :60
+    if (!(GVEC_PROFILE_SKIP & 16)) update_stats();                                                       // :65,170-179
     check_game_over();
     return 0u;
   }

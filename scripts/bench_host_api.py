@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Host-buffer API latencies (read_state / step / vector env step) at a modest batch: what a Python consumer sees."""
+"""What a Python consumer sees: host-buffer API latencies (read_state / step), and the gym-style vector env in its
+two modes - host numpy (state read-back over PCIe + numpy observation building) and device_outputs (gym kernels,
+CUDA tensors, actions decoded on the device).   usage: scripts/bench_host_api.py [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 import generalsreinforcementlearning_amd as g
 from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
 
@@ -15,13 +18,34 @@ def t(f, n=20):
     for _ in range(n): f()
     return (time.perf_counter() - t0) / n * 1e3
 print(f"B={B}: game_state() {t(lambda: e.game_state()):.2f} ms | step(host acts) {t(lambda: e.step(acts)):.2f} ms | "
-      f"step+mask {t(lambda: e.step(acts, want_mask=True)):.2f} ms | legal_action_mask_bits {t(lambda: e.legal_action_mask_bits()):.2f} ms")
+      f"step+mask {t(lambda: e.step(acts, want_mask=True)):.2f} ms | legal_action_mask_bits {t(lambda: e.legal_action_mask_bits()):.2f} ms", flush=True)
+del e
+
 env = GeneralsVecEnv(num_envs=B, board_width=20, board_height=20, max_players=4)
 obs, info = env.reset(seed=3)
+holder = [info]
 def vstep():
-    m = info_holder[0]["valid_actions_mask"]
-    a = np.array([np.flatnonzero(r)[0] if r.any() else 0 for r in m[: 64]] + [0] * (B - 64))
+    m = holder[0]["valid_actions_mask"]
+    a = np.argmax(m, axis=1)                      # the first valid action of every env (0 where there is none)
     o, r, term, trunc, inf = env.step(a)
-    info_holder[0] = inf
-info_holder = [info]
-print(f"GeneralsVecEnv.step {t(vstep, 10):.2f} ms  ({B / t(vstep, 10) * 1e3 / 1e6:.2f} M env-steps/s through the gym-style host API)")
+    holder[0] = inf
+ms = t(vstep, 10)
+print(f"GeneralsVecEnv.step (host numpy mode)   {ms:8.2f} ms  ({B / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
+env.close()
+
+for BB in sorted({B, 65536}):
+    env = GeneralsVecEnv(num_envs=BB, board_width=20, board_height=20, max_players=4, device_outputs=True)
+    obs, info = env.reset(seed=3)
+    holder = [info]
+    def dstep():
+        a = torch.argmax(holder[0]["valid_actions_mask"].to(torch.uint8), dim=1)
+        o, r, term, trunc, inf = env.step(a)
+        holder[0] = inf
+    def timed(n):
+        dstep(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): dstep()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    ms = timed(20)
+    print(f"GeneralsVecEnv.step (device_outputs, B={BB}) {ms:8.3f} ms  ({BB / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
+    env.close()
