@@ -121,8 +121,9 @@ __device__ __forceinline__ void load_turn(BT& b, const uint32_t* hdr, const uint
     b.issue_hdr(hdr);
     b.load_army_narrow(army);
     b.load_planes(rows, fd, zeros);
+    b.decode_hdr_scalar(hdr);   // SMEM: in flight with the vector loads above
     b.land();
-    b.decode_hdr();
+    b.land_scalars();
     b.load_army_wide_if_flagged(army);
   } else {
     b.load_hdr(hdr);

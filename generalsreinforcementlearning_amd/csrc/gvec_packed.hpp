@@ -58,13 +58,15 @@ __device__ __forceinline__ uint32_t row_last(uint32_t v) {
 __device__ __forceinline__ uint32_t kth_set_bit(uint32_t w, uint32_t r) {
   uint32_t pos = 0u;
 #pragma unroll
-  for (int width = 16; width >= 1; width >>= 1) {
+  for (int width = 16; width >= 2; width >>= 1) {
     const uint32_t c = (uint32_t)__builtin_popcount(__builtin_amdgcn_ubfe(w, pos, (uint32_t)width));
-    const bool ge = r >= c;
-    r = ge ? r - c : r;
-    pos = ge ? pos + (uint32_t)width : pos;
+    const uint32_t d = r - c;          // borrows iff r < c
+    const bool lt = r < c;
+    r = lt ? r : d;
+    pos = lt ? pos : (pos | (uint32_t)width);   // pos is a multiple of 2 * width: OR == ADD
   }
-  return pos;
+  // last level: the bit at pos is the one iff it is set and r == 0
+  return pos | ((r >= ((w >> pos) & 1u)) ? 1u : 0u);
 }
 
 // ---- the random agent's mixer (DESIGN.md "Synthetic inputs"; mirrored by the oracle's ora_amix) --------
@@ -158,6 +160,25 @@ struct PBoard {
     alive = rdlane(hv, H_STATUS) & 0xFFu;
     recipW = (int)rdlane(hv, H_RECIPW);
   }
+  // The same fields through the scalar cache (s_load: no vector instruction, no cross-lane read).  The header
+  // is only written by this wave's own final store, and the scalar cache is invalidated between launches.
+  __device__ __forceinline__ void decode_hdr_scalar(const uint32_t* hdr_env) {
+    typedef const __attribute__((address_space(4))) uint32_t* kptr;
+    kptr k = (kptr)hdr_env;
+    turn = (int)k[H_TURN];
+    const uint32_t dims = k[H_DIMS];
+    W = (int)(dims & 0xFFu);
+    H = (int)((dims >> 8) & 0xFFu);
+    P = (int)((dims >> 16) & 0xFFu);
+    hflags = dims >> 24;
+    N = W * H;
+    alive = k[H_STATUS] & 0xFFu;
+    recipW = (int)k[H_RECIPW];
+  }
+  // keeps the scalar loads above from being sunk to their first use (a late s_load is a late round trip)
+  __device__ __forceinline__ void land_scalars() {
+    asm volatile("" : "+s"(turn), "+s"(W), "+s"(H), "+s"(P), "+s"(hflags), "+s"(alive), "+s"(recipW));
+  }
   __device__ __forceinline__ void load_hdr(const uint32_t* hdr_env) {
     issue_hdr(hdr_env);
     decode_hdr();
@@ -191,8 +212,7 @@ struct PBoard {
   __device__ __forceinline__ void store_hdr(uint32_t* hdr_env, uint32_t last_err) {
     hdr_set(H_TURN, (uint32_t)turn);
     hdr_set(H_DIMS, (uint32_t)W | ((uint32_t)H << 8) | ((uint32_t)P << 16) | (hflags << 24));
-    hdr_set(H_STATUS, alive | (last_err << 16));
-    hdr_set(H_RECIPW, (uint32_t)recipW);
+    hdr_set(H_STATUS, alive | (last_err << 16));  // (H_RECIPW is a function of W: it rides along in hv unchanged)
     if (lane_id() < HDR_DW) hdr_env[lane_id()] = hv;
   }
 
@@ -468,10 +488,10 @@ struct PBoard {
 #pragma unroll
     for (int k = 0; k < NR; ++k) listed_alive |= lane_flag(alive, k) ? lst[k] : 0u;
     listed_alive = or_rows(listed_alive);
-    const uint32_t normal = ~(gen | city | mtn) & valid;
     const uint32_t mg = (pg > 0) ? (listed_alive & gen) : 0u;
     const uint32_t mc = (pc > 0) ? (listed_alive & city) : 0u;
-    const uint32_t mn = (grow && pn > 0) ? (listed_alive & normal) : 0u;
+    uint32_t mn = 0u;
+    if (grow && pn > 0) mn = listed_alive & ~(gen | city | mtn) & valid;  // wave-uniform: one turn in `interval`
     chg |= mg | mc | mn;  // :59-61 (prod > 0 only)
     const int an = (grow && pn > 0) ? pn : pc;
     if (pg == pc && pc == an) {  // one rate for every producing tile: one gather per slot
