@@ -44,7 +44,28 @@
 // wave-uniform; the backend moves a run-time lane select to M0)
 extern "C" __device__ int gvec_llvm_writelane(int value, int lane, int vdst_in) __asm("llvm.amdgcn.writelane.i32");
 
+// Streaming (non-temporal) cache policy on the turn kernels' once-per-launch accesses, by class (bits):
+// 1 loads, 2 mask stores, 4 plane stores, 8 army stores.  One-process A/B at 262,144 boards 20x20 4P: nt LOADS
+// cost 12 %, nt stores gain 3-4 % (the stored lines need not displace what the next loads want).
+#ifndef GVEC_NT
+#define GVEC_NT 14
+#endif
+#define GVEC_NT_MASK 2
+#define GVEC_NT_PLANE 4
+#define GVEC_NT_ARMY 8
+
 namespace gvec {
+
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr ((GVEC_NT & 1) != 0) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <int CLASS, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  if constexpr ((GVEC_NT & CLASS) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 // ---- resident record layout (per env) -------------------------------------------------
 // hdr  : HDR_DW u32      planes : M*FD u32 (+pad to 4), plane-major [m][i]
@@ -136,11 +157,11 @@ __device__ __forceinline__ void army_load_narrow(int32_t (&army)[NSLOT], const u
   const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
   for (int k = 0; k < NSLOT / 2; ++k) {
-    const uint32_t w = n[64 * k + lane];
+    const uint32_t w = ld_stream(n + 64 * k + lane);
     army[2 * k] = (int32_t)(w & 0xFFFFu);
     army[2 * k + 1] = (int32_t)(w >> 16);
   }
-  if constexpr ((NSLOT & 1) != 0) army[NSLOT - 1] = (int32_t)reinterpret_cast<const uint16_t*>(n + 64 * (NSLOT / 2))[lane];
+  if constexpr ((NSLOT & 1) != 0) army[NSLOT - 1] = (int32_t)ld_stream(reinterpret_cast<const uint16_t*>(n + 64 * (NSLOT / 2)) + lane);
 }
 template <int NSLOT>
 __device__ __forceinline__ void army_load_wide(int32_t (&army)[NSLOT], const int32_t* w) {
@@ -160,8 +181,8 @@ template <int NSLOT>
 __device__ __forceinline__ void army_store_narrow(const int32_t (&army)[NSLOT], uint32_t* n) {
   const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
-  for (int k = 0; k < NSLOT / 2; ++k) n[64 * k + lane] = (uint32_t)army[2 * k] | ((uint32_t)army[2 * k + 1] << 16);
-  if constexpr ((NSLOT & 1) != 0) reinterpret_cast<uint16_t*>(n + 64 * (NSLOT / 2))[lane] = (uint16_t)army[NSLOT - 1];
+  for (int k = 0; k < NSLOT / 2; ++k) st_stream<GVEC_NT_ARMY>(n + 64 * k + lane, (uint32_t)army[2 * k] | ((uint32_t)army[2 * k + 1] << 16));
+  if constexpr ((NSLOT & 1) != 0) st_stream<GVEC_NT_ARMY>(reinterpret_cast<uint16_t*>(n + 64 * (NSLOT / 2)) + lane, (uint16_t)army[NSLOT - 1]);
 }
 template <int NSLOT>
 __device__ __forceinline__ void army_store_wide(const int32_t (&army)[NSLOT], int32_t* w) {

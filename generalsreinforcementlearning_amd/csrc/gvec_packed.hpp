@@ -227,21 +227,21 @@ struct PBoard {
     for (int k = 0; k < NR; ++k) {
       const bool on = in && (k * PPR + row() < MAXP);
       const uint32_t* gp = on ? rows_env + (row() * fd + col()) : zeros;  // packed: plane (base + row), dword col
-      own[k] = gp[(PL::OWN + k * PPR) * fd];
-      lst[k] = gp[(PL::LST + k * PPR) * fd];
-      vis[k] = gp[(PL::VIS + k * PPR) * fd];
+      own[k] = ld_stream(gp + (PL::OWN + k * PPR) * fd);
+      lst[k] = ld_stream(gp + (PL::LST + k * PPR) * fd);
+      vis[k] = ld_stream(gp + (PL::VIS + k * PPR) * fd);
     }
-    chg = gs[PL::CHG * fd];
-    vch = gs[PL::VCH * fd];
-    gt1 = gs[PL::GT1 * fd];
-    gen = gs[PL::GEN * fd];
-    city = gs[PL::CITY * fd];
-    mtn = gs[PL::MTN * fd];
-    valid = gs[PL::VALID * fd];
-    ncol0 = gs[PL::NCOL0 * fd];
-    ncolL = gs[PL::NCOLL * fd];
+    chg = ld_stream(gs + PL::CHG * fd);
+    vch = ld_stream(gs + PL::VCH * fd);
+    gt1 = ld_stream(gs + PL::GT1 * fd);
+    gen = ld_stream(gs + PL::GEN * fd);
+    city = ld_stream(gs + PL::CITY * fd);
+    mtn = ld_stream(gs + PL::MTN * fd);
+    valid = ld_stream(gs + PL::VALID * fd);
+    ncol0 = ld_stream(gs + PL::NCOL0 * fd);
+    ncolL = ld_stream(gs + PL::NCOLL * fd);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) ok[d] = gs[(PL::OK + d) * fd];
+    for (int d = 0; d < 4; ++d) ok[d] = ld_stream(gs + (PL::OK + d) * fd);
   }
   // The planes from GEN on change only when the env is re-dealt (with_types).
   __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
@@ -250,17 +250,17 @@ struct PBoard {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       if (in && (k * PPR + row() < MAXP)) {
-        gp[(PL::OWN + k * PPR) * fd] = own[k];
-        gp[(PL::LST + k * PPR) * fd] = lst[k];
-        gp[(PL::VIS + k * PPR) * fd] = vis[k];
+        st_stream<GVEC_NT_PLANE>(gp + (PL::OWN + k * PPR) * fd, own[k]);
+        st_stream<GVEC_NT_PLANE>(gp + (PL::LST + k * PPR) * fd, lst[k]);
+        st_stream<GVEC_NT_PLANE>(gp + (PL::VIS + k * PPR) * fd, vis[k]);
       }
     }
     const int lane = lane_id();
     if (lane < fd) {  // lanes 0..fd-1 are row 0, columns 0..fd-1 (fd <= ROWL)
       uint32_t* g = rows_env + lane;
-      g[PL::CHG * fd] = chg;
-      g[PL::VCH * fd] = vch;
-      g[PL::GT1 * fd] = gt1;
+      st_stream<GVEC_NT_PLANE>(g + PL::CHG * fd, chg);
+      st_stream<GVEC_NT_PLANE>(g + PL::VCH * fd, vch);
+      st_stream<GVEC_NT_PLANE>(g + PL::GT1 * fd, gt1);
       if (with_types) {
         g[PL::GEN * fd] = gen;
         g[PL::CITY * fd] = city;
@@ -700,7 +700,7 @@ struct PBoard {
       if (in && p < pstride && p < MAXP) {
         uint32_t* g = legal_env + (size_t)p * (4 * fd) + col();
 #pragma unroll
-        for (int d = 0; d < 4; ++d) g[d * fd] = m[k][d];
+        for (int d = 0; d < 4; ++d) st_stream<GVEC_NT_MASK>(g + d * fd, m[k][d]);
       }
     }
   }
