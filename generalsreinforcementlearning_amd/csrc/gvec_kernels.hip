@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];  // per wave: the action phase's army copy
   using B = Turn<MAXP, NSLOT>;
+  __shared__ uint32_t act_scratch[WAVES_PER_BLOCK][B::ACT_SCRATCH_DW];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   }
   B b;
   b.larmy = army_shadow[wave];
+  b.lscr = act_scratch[wave];
   const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
   load_turn<true>(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD, A.zeros);
   b.small = !(b.hflags & HF_WIDE);  // one turn from armies <= 65535: every sum of the turn stays below 2^23
@@ -258,11 +260,13 @@ template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) void rollout_kernel(StepArgs A) {
   __shared__ int32_t army_shadow[WAVES_PER_BLOCK][NSLOT * 64];
   using B = Turn<MAXP, NSLOT>;
+  __shared__ uint32_t act_scratch[WAVES_PER_BLOCK][B::ACT_SCRATCH_DW];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (env >= A.num_envs) return;
   B b;
   b.larmy = army_shadow[wave];
+  b.lscr = act_scratch[wave];
   const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
   load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd, A.zeros);
   uint32_t m[B::NR][4];

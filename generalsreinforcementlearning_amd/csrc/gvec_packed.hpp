@@ -25,6 +25,10 @@
 #ifndef GVEC_PROFILE_SKIP
 #define GVEC_PROFILE_SKIP 0
 #endif
+// 1: the action phase runs on lanes when no two moves of a turn share a tile (act_vector); 0: always sequential (A/B)
+#ifndef GVEC_ACT_VECTOR
+#define GVEC_ACT_VECTOR 1
+#endif
 
 namespace gvec {
 
@@ -88,6 +92,9 @@ struct PBoard {
   static constexpr int ROWL = 64 / PPR;               // lanes per row
   static constexpr int NR = (MAXP + PPR - 1) / PPR;   // registers per plane kind
   static constexpr bool FULL_ROWS = (2 * NSLOT >= ROWL);  // a plane can fill its row: shifts must not cross rows
+  // LDS scratch of the vector action phase: three ROWL-dword tile bitmaps (candidate tiles, changed, captured) and one
+  // 64-dword image per packed ownership register (the bits captures set)
+  static constexpr int ACT_SCRATCH_DW = 3 * ROWL + 64 * NR;
 
   uint32_t own[NR], lst[NR], vis[NR];         // packed: row r of register k = player k*PPR + r
   uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
@@ -96,6 +103,7 @@ struct PBoard {
   int32_t army[NSLOT];                        // tile domain, as in Board
   uint32_t hv;
   int32_t* larmy;                             // LDS shadow of the armies during the action phase: tile t at larmy[t]
+  uint32_t* lscr = nullptr;                   // ACT_SCRATCH_DW dwords of LDS for the vector action phase (null: sequential only)
   int W, H, P, N, turn, recipW;
   uint32_t alive, hflags;
   // every army stays below 2^23 until the board is stored (true for one turn from a NARROW load): the
@@ -590,6 +598,113 @@ struct PBoard {
       army_set(tt, ta - n);  // :85
     }
   }
+  // ---- the action phase, all players at once ---------------------------------------------------------------
+  // ActionProcessor.ProcessActions applies the moves in PlayerID order, each against the board the lower ids left
+  // behind.  When no tile is touched by two of this turn's moves - the overwhelmingly common case - every move only sees
+  // pre-turn state, and the whole phase runs once on lanes (lane p = player p) instead of P times on the scalar unit:
+  // Validate's state-dependent half (core/action.go:82-98), ApplyMoveAction (core/movement.go:23-89) and the captures'
+  // bookkeeping.  Tile coincidence is detected exactly (every candidate move ORs its two tile bits into an LDS bitmap:
+  // all distinct iff the bitmap's popcount is twice the number of candidates); otherwise - returns false, nothing
+  // modified - the caller takes the sequential path below.  Needs the armies in the LDS shadow.
+  __device__ __forceinline__ bool act_vector(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders, uint32_t& elim_seen) {
+    const int lane = lane_id();
+    uint32_t* s_cand = lscr;
+    uint32_t* s_chg = lscr + ROWL;
+    uint32_t* s_cap = lscr + 2 * ROWL;
+    uint32_t* s_own = lscr + 3 * ROWL;
+#pragma unroll
+    for (int i = 0; i < (ACT_SCRATCH_DW + 63) / 64; ++i)
+      if (64 * i + lane < ACT_SCRATCH_DW) lscr[64 * i + lane] = 0u;
+    const uint32_t m = av.meta;
+    const bool active = lane < P && (m & 16u) != 0u && ((alive >> lane) & 1u) != 0u;  // action_processor.go:56-60 (H2)
+    const uint32_t scode = m & 15u;
+    const bool cand = active && scode == 0u;
+    const int ft = cand ? av.ft : 0, tt = cand ? av.tt : 0;
+    const uint32_t fbit = 1u << (ft & 31), tbit = 1u << (tt & 31);
+    const int fcol = ft >> 5, tcol = tt >> 5;
+    wave_lds_fence();
+    if (cand) {
+      atomicOr(&s_cand[fcol], fbit);
+      atomicOr(&s_cand[tcol], tbit);
+    }
+    wave_lds_fence();
+    const uint32_t cb = (lane < ROWL) ? s_cand[lane & (ROWL - 1)] : 0u;
+    const int distinct = (int)rdlane(row_scan_add<ROWL>((uint32_t)__builtin_popcount(cb)), ROWL - 1);
+    const int ncand = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand));
+    if (distinct != 2 * ncand) return false;  // two moves meet on a tile: order matters
+    // pre-turn facts of my move
+    const int32_t fa = larmy[ft], ta = larmy[tt];
+    const int myrow = (lane % PPR) * ROWL;
+    uint32_t w_ft = 0u, w_tt = 0u;  // my own ownership row at the source / target dword
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t g = bperm((myrow + fcol) << 2, own[k]), h = bperm((myrow + tcol) << 2, own[k]);
+      w_ft = (lane / PPR == k) ? g : w_ft;
+      w_tt = (lane / PPR == k) ? h : w_tt;
+    }
+    const bool own_ft = ((w_ft >> (ft & 31)) & 1u) != 0u;
+    const bool mine_tt = ((w_tt >> (tt & 31)) & 1u) != 0u;
+    const bool mtn_tt = ((bperm(tcol << 2, mtn) >> (tt & 31)) & 1u) != 0u;
+    const bool gen_tt = ((bperm(tcol << 2, gen) >> (tt & 31)) & 1u) != 0u;
+    // MoveAction.Validate, the state-dependent half, in the reference's order (action.go:82-98)
+    uint32_t code = scode;
+    code = (cand && mtn_tt) ? GVEC_ERR_TARGET_IS_MOUNTAIN : code;
+    code = (cand && fa <= 1) ? GVEC_ERR_INSUFFICIENT_ARMY : code;
+    code = (cand && !own_ft) ? GVEC_ERR_NOT_OWNED : code;
+    const bool ok = cand && code == 0u;
+    {  // the FIRST error in PlayerID order (action_processor.go:66-77)
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(active && code != 0u);
+      if (em && !first_err) first_err = rdlane(code, (int)__builtin_ctzll(em));
+    }
+    // core.ApplyMoveAction (movement.go:40-86)
+    int32_t n = (m & 32u) ? (fa >> 1) : (fa - 1);  // fa >= 2 where it matters
+    n = n < 1 ? 1 : n;
+    const bool capture = ok && !mine_tt && n > ta;  // ties favour the defender
+    const int32_t new_ta = mine_tt ? ta + n : (capture ? n - ta : ta - n);
+    if (ok) {
+      larmy[ft] = fa - n;
+      larmy[tt] = new_ta;
+      atomicOr(&s_chg[fcol], fbit);  // :57-60
+      atomicOr(&s_chg[tcol], tbit);
+    }
+    if (capture) {
+      atomicOr(&s_cap[tcol], tbit);                            // action_processor.go:84-86
+      atomicOr(&s_own[64 * (lane / PPR) + myrow + tcol], tbit);  // :69-82 the tile is mine now
+    }
+    wave_lds_fence();
+    const uint32_t capbits = s_cap[col()];
+    chg |= s_chg[col()];
+    vch |= capbits;
+    uint32_t own_before[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      own_before[k] = own[k];
+      own[k] = (own[k] & ~capbits) | s_own[64 * k + lane];
+    }
+    // core.ProcessCaptures (movement.go:100-118): captured generals with a previous owner, in PlayerID order
+    unsigned long long el = __builtin_amdgcn_ballot_w64(capture && gen_tt);
+    uint32_t owner_bits = 0u;  // bit q: player q owned the captured tile (pre-turn; none: neutral general, no order)
+    if (el) {                  // rare: only now is the previous owner needed
+#pragma unroll
+      for (int q = 0; q < MAXP; ++q) {
+        const uint32_t g = bperm((((q % PPR) * ROWL) + tcol) << 2, own_before[q / PPR]);
+        owner_bits |= ((g >> (tt & 31)) & 1u) << q;
+      }
+      el = __builtin_amdgcn_ballot_w64(capture && gen_tt && owner_bits != 0u);
+    }
+    while (el) {
+      const int p = (int)__builtin_ctzll(el);
+      el &= el - 1ull;
+      const int prev = (int)__builtin_ctz(rdlane(owner_bits, p));
+      if (!((elim_seen >> prev) & 1u)) {
+        orders |= (uint64_t)((uint32_t)prev | ((uint32_t)p << 4)) << (8 * n_orders);
+        n_orders++;
+        elim_seen |= 1u << prev;
+      }
+    }
+    return true;
+  }
+
   template <int PID>
   __device__ __forceinline__ void act_chain(const ActVec& av, uint32_t& first_err, uint64_t& orders, int& n_orders,
                                             uint32_t& elim_seen) {
@@ -639,7 +754,8 @@ struct PBoard {
     const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
     if (present && !(GVEC_PROFILE_SKIP & 4)) {  // a turn where nobody moves touches no army
       army_to_lds();
-      act_chain<0>(av, first_err, orders, n_orders, elim_seen);
+      if (!(GVEC_ACT_VECTOR && lscr && act_vector(av, first_err, orders, n_orders, elim_seen)))
+        act_chain<0>(av, first_err, orders, n_orders, elim_seen);
       army_from_lds();
     }
     if (n_orders > 0) {  // engine.go:101-109
