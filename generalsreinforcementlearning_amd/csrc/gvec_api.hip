@@ -123,6 +123,7 @@ StepArgs base_args(const gvec_handle* h) {
   a.prod_city = h->cfg.prod_city;
   a.prod_normal = h->cfg.prod_normal;
   a.interval = h->cfg.normal_growth_interval;
+  a.interval_magic = (uint32_t)((0x100000000ull + (uint64_t)a.interval - 1) / (uint64_t)a.interval);
   a.turns = 1;
   a.agent_noop = h->agent_noop;
   a.agent_half = h->agent_half;

@@ -118,6 +118,7 @@ struct StepArgs {
   int32_t num_envs, fd, row_dw, mask_dw, pool_size;  // fd = dwords per plane = ceil(max tiles / 32)
   int32_t pstride;  // players per env in actions / legal buffers (gvec_config.max_players)
   int32_t prod_general, prod_city, prod_normal, interval;
+  uint32_t interval_magic;  // ceil(2^32 / interval)
   int32_t turns, invalid_permille;
   uint32_t agent_noop, agent_half;  // gvec_set_agent_mix thresholds (of 65536)
   uint32_t flags, seed_lo, seed_hi, pool_seed_lo, pool_seed_hi;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
 constexpr int rollout_waves(int maxp, int nslot) {
   const int ppr = (nslot <= 7) ? 4 : 2;
   const int nr = (maxp + ppr - 1) / ppr;
-  const int need = 3 * nr + 13 + nr + nslot + 4 * nr + (nslot >= 10 ? 60 : 44);
+  const int need = 3 * nr + 13 + nr + nslot + 4 * nr + (nslot >= 16 ? 100 : nslot >= 10 ? 68 : 44);
   const int alloc = (need + 7) / 8 * 8;
   const int w = 512 / alloc;
   return w > 8 ? 8 : (w < 2 ? 2 : w);

@@ -490,8 +490,19 @@ struct PBoard {
   }
 
   // ---- ProductionManager.ProcessTurnProduction (production_manager.go:26-101) ------------------------
-  __device__ __forceinline__ void production(int pg, int pc, int pn, int interval) {
-    const bool grow = (turn % interval) == 0;  // :27
+  // interval_magic = ceil(2^32 / interval) (host): turn % interval without the vector unit's float reciprocal
+  // (a scalar `%` by a run-time value compiles to v_cvt / v_rcp / v_mul / v_cvt + 20 scalar instructions).
+  // q = mulhi(turn, magic) is floor(turn / interval) or one more while turn * interval < 2^32; beyond that the plain `%`.
+  __device__ __forceinline__ void production(int pg, int pc, int pn, int interval, uint32_t interval_magic) {
+    bool grow;
+    if ((uint32_t)turn < 0x10000u && (uint32_t)interval < 0x10000u) {
+      const uint32_t q = __umulhi((uint32_t)turn, interval_magic);  // wave-uniform operands: s_mul_hi_u32
+      int32_t r = turn - (int32_t)(q * (uint32_t)interval);
+      r = r < 0 ? r + interval : r;
+      grow = r == 0;
+    } else {
+      grow = (turn % interval) == 0;  // :27
+    }
     uint32_t listed_alive = 0u;                // :39-45: lists of alive players, owner NOT re-checked (H7)
 #pragma unroll
     for (int k = 0; k < NR; ++k) listed_alive |= lane_flag(alive, k) ? lst[k] : 0u;
@@ -515,7 +526,8 @@ struct PBoard {
   // ---- WinConditionChecker.CheckGameOver (rules/win_conditions.go:21-57) ---------------------------
   __device__ __forceinline__ void check_game_over() {
     const int na = __builtin_popcount(alive);
-    const bool over = (P > 1) ? (na <= 1) : (na == 0);  // originalPlayers == len(Players)
+    const int most = (P > 1) ? 1 : 0;  // originalPlayers == len(Players): over when at most one (none, for a 1-player board) is alive
+    const bool over = na <= most;
     hflags = over ? (hflags | HF_DONE) : (hflags & ~HF_DONE);
     // the winner is re-derived from Alive on read-back, like Engine.GetWinner (engine.go:248-263)
   }
@@ -766,7 +778,7 @@ struct PBoard {
       aborted = true;
       return first_err;
     }
-    if (!(GVEC_PROFILE_SKIP & 8)) production(A.prod_general, A.prod_city, A.prod_normal, A.interval);  // :60
+    if (!(GVEC_PROFILE_SKIP & 8)) production(A.prod_general, A.prod_city, A.prod_normal, A.interval, A.interval_magic);  // :60
     if (!(GVEC_PROFILE_SKIP & 16)) update_stats();                                                       // :65,170-179
     check_game_over();
     return 0u;
