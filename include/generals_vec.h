@@ -117,7 +117,10 @@ typedef struct gvec_handle gvec_handle;
  * Shapes: tile planes [n][max_width*max_height]; per-player [n][max_players];
  * scalars [n]. */
 typedef struct gvec_state_view {
-  int32_t* army;         /* Tile.Army                      (core/board.go:9)            */
+  int32_t* army;         /* Tile.Army (core/board.go:9).  A Go int is 64-bit; this engine computes in
+                            int32 and stores exactly (u16 or int32 per env): a board whose armies
+                            pass 2^31-1 would wrap here and not in Go - unreachable by play
+                            (production adds 1 per tile per turn), reachable by gvec_write_state */
   int8_t*  owner;        /* Tile.Owner, -1 neutral         (core/board.go:8)            */
   uint8_t* type;         /* Tile.Type                      (core/board.go:10)           */
   uint8_t* visible;      /* Tile.VisibleBitfield, bit p    (core/board.go:11)           */

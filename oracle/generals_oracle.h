@@ -16,7 +16,12 @@
  * the reference's own *_test.go files, transcribed under tests/golden/ (see
  * tests/golden/README.md for the file:line of every vector).  Fog of war and the
  * H4-H8 hazards of SURVEY.md have no asserting test in the reference: for those
- * the oracle rests on line-by-line restatement only ("parity unpinned" for fog).
+ * the oracle rests on line-by-line restatement only ("parity unpinned" for fog by
+ * the reference's own tests).  Fog has two further checks of its own
+ * (tests/test_fog_cross_checks.py): the reference's LEGACY twin of the update
+ * (visibility.go:19-144) is restated separately below and must agree with the
+ * optimized restatement on every turn, and a restatement-free property (visibility
+ * = 3x3 dilation of last turn's lists while lists match the board).
  */
 #ifndef GENERALS_ORACLE_H
 #define GENERALS_ORACLE_H
