@@ -135,10 +135,16 @@ class GeneralsVecEnv:
     reset() -> (obs, info);  step(actions[B]) -> (obs, reward, terminated, truncated, info)."""
 
     def __init__(self, num_envs, board_width=15, board_height=15, max_players=2, fog_of_war=True, max_turns=500,
-                 seed=0, device=0, board_pool=1024, device_outputs=False):
-        """device_outputs=True: observation / mask / reward / flags are torch tensors on the GPU, produced by the
-        gym kernels (gvec_gym_observe / gvec_gym_actions), and `step` takes a CUDA int64 tensor of actions: no
-        board state crosses PCIe.  False (default): numpy arrays built on the host from a state read-back."""
+                 seed=0, device=0, board_pool=1024, device_outputs=False, numpy_reference=False):
+        """Three modes, identical outputs (tests/test_vector_env.py):
+        device_outputs=True  observation / mask / reward / flags are torch tensors on the GPU, produced by the gym kernels
+                             (gvec_gym_observe / gvec_gym_actions); `step` takes a CUDA int64 tensor of actions: no board
+                             state crosses PCIe.
+        default              numpy arrays in, numpy arrays out - the same kernels, their outputs copied to pinned host
+                             buffers (one D2H of the observation per step instead of a state read-back + numpy rebuild).
+        numpy_reference=True numpy arrays built on the host from a state read-back with the pure functions above: the
+                             readable restatement the other two modes are tested against (also what runs when torch
+                             has no GPU, e.g. on the oracle-backed engine of the CPU tests)."""
         self.num_envs = num_envs
         self.board_width, self.board_height = board_width, board_height
         self.board_size = board_width * board_height
@@ -160,7 +166,14 @@ class GeneralsVecEnv:
         self._obs_bufs = [np.zeros((num_envs, 9, board_height, board_width), np.float32) for _ in range(2)]
         self._obs_flip = 0
         self.device_outputs = bool(device_outputs)
-        if self.device_outputs:
+        self._via_kernels = False
+        if not self.device_outputs and not numpy_reference and hasattr(self.engine, "L"):
+            try:
+                import torch
+                self._via_kernels = torch.cuda.is_available()
+            except ImportError:
+                self._via_kernels = False
+        if self.device_outputs or self._via_kernels:
             import torch
             self._t = torch
             dev = torch.device("cuda", device)
@@ -175,6 +188,10 @@ class GeneralsVecEnv:
             self._d_needs_reset = z(num_envs, torch.uint8)
             self._d_acts = z((num_envs, max_players, 8), torch.uint8)
             self._d_played, self._d_invalid, self._d_error = (z(num_envs, torch.uint8) for _ in range(3))
+            if self._via_kernels:   # pinned landing buffers for the default (numpy) mode
+                pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+                self._h_obs = [pin((num_envs, 9, board_height, board_width), torch.float32) for _ in range(2)]
+                self._h_mask = [pin((num_envs, n * 5), torch.bool) for _ in range(2)]
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _read(self):
@@ -211,7 +228,9 @@ class GeneralsVecEnv:
 
     def _step_device(self, actions):
         t, e = self._t, self.engine
-        actions = t.as_tensor(actions, dtype=t.int64, device=self._dev).reshape(self.num_envs).contiguous()
+        if isinstance(actions, np.ndarray):
+            actions = t.from_numpy(np.ascontiguousarray(actions, np.int64))
+        actions = t.as_tensor(actions, dtype=t.int64).to(self._dev).reshape(self.num_envs).contiguous()
         resetting = self._d_needs_reset.clone()
         # opponents: the on-device random agent writes every slot; the learner's slot is then overwritten
         check(e.L.gvec_agent_actions(e.h, self._seed + 1000 * self._episode + 1, 0, self._d_acts.data_ptr(), 1), "gvec_agent_actions")
@@ -231,6 +250,18 @@ class GeneralsVecEnv:
                 "error": self._d_error.bool(), "winner": t.where(terminated, self._d_winner, t.full_like(self._d_winner, -1)), "reset": rs}
         return obs, reward, terminated, truncated, info
 
+    def _to_numpy(self, obs, info):
+        """The device path's outputs as numpy arrays (default mode): observation and mask land in pinned buffers that
+        alternate, so the arrays returned by step k stay intact until step k + 2."""
+        i = self._obs_flip
+        self._h_obs[i].copy_(obs, non_blocking=True)
+        self._h_mask[i].copy_(info["valid_actions_mask"], non_blocking=True)
+        out = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in info.items() if k != "valid_actions_mask"}
+        self._t.cuda.current_stream(self._dev).synchronize()
+        out["valid_actions_mask"] = self._h_mask[i].numpy()
+        self.valid_actions_mask = out["valid_actions_mask"]
+        return self._h_obs[i].numpy(), out
+
     def reset(self, seed=None):
         if seed is not None:
             self._seed = seed
@@ -238,6 +269,9 @@ class GeneralsVecEnv:
         self.engine.build_board_pool(self._pool, self._seed * 7919 + 5)
         if self.device_outputs:
             return self._reset_device()
+        if self._via_kernels:
+            obs, info = self._reset_device()
+            return self._to_numpy(obs, info)
         self.turn_count[:] = 0
         self._needs_reset[:] = False
         view, self._stats = self._read()
@@ -248,6 +282,10 @@ class GeneralsVecEnv:
     def step(self, actions):
         if self.device_outputs:
             return self._step_device(actions)
+        if self._via_kernels:
+            obs, reward, terminated, truncated, info = self._step_device(np.asarray(actions, np.int64))
+            obs, info = self._to_numpy(obs, info)
+            return obs, reward.cpu().numpy(), terminated.cpu().numpy(), truncated.cpu().numpy(), info
         B, W, H = self.num_envs, self.board_width, self.board_height
         actions = np.asarray(actions, np.int64).reshape(B)
         resetting = self._needs_reset.copy()

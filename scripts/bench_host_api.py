@@ -21,17 +21,19 @@ print(f"B={B}: game_state() {t(lambda: e.game_state()):.2f} ms | step(host acts)
       f"step+mask {t(lambda: e.step(acts, want_mask=True)):.2f} ms | legal_action_mask_bits {t(lambda: e.legal_action_mask_bits()):.2f} ms", flush=True)
 del e
 
-env = GeneralsVecEnv(num_envs=B, board_width=20, board_height=20, max_players=4)
-obs, info = env.reset(seed=3)
-holder = [info]
-def vstep():
-    m = holder[0]["valid_actions_mask"]
-    a = np.argmax(m, axis=1)                      # the first valid action of every env (0 where there is none)
-    o, r, term, trunc, inf = env.step(a)
-    holder[0] = inf
-ms = t(vstep, 10)
-print(f"GeneralsVecEnv.step (host numpy mode)   {ms:8.2f} ms  ({B / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
-env.close()
+for label, kw in (("numpy_reference (state read-back + numpy rebuild)", dict(numpy_reference=True)),
+                  ("default: numpy in / out over the gym kernels", dict())):
+    env = GeneralsVecEnv(num_envs=B, board_width=20, board_height=20, max_players=4, **kw)
+    obs, info = env.reset(seed=3)
+    holder = [info]
+    def vstep():
+        m = holder[0]["valid_actions_mask"]
+        a = np.argmax(m, axis=1)                      # the first valid action of every env (0 where there is none)
+        o, r, term, trunc, inf = env.step(a)
+        holder[0] = inf
+    ms = t(vstep, 10)
+    print(f"GeneralsVecEnv.step ({label})   {ms:8.2f} ms  ({B / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
+    env.close()
 
 for BB in sorted({B, 65536}):
     env = GeneralsVecEnv(num_envs=BB, board_width=20, board_height=20, max_players=4, device_outputs=True)

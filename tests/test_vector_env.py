@@ -296,7 +296,7 @@ def test_device_vector_env_equals_host_vector_env(fog, P):
     every output of every step, bit for bit - invalid actions, half moves, terminations, truncations and re-deals included."""
     import torch
     kw = dict(board_width=9, board_height=8, max_players=P, fog_of_war=fog, max_turns=30, seed=5, board_pool=64)
-    host = V.GeneralsVecEnv(48, **kw)
+    host = V.GeneralsVecEnv(48, numpy_reference=True, **kw)
     dev = V.GeneralsVecEnv(48, device_outputs=True, **kw)
     ho, hi = host.reset()
     do, di = dev.reset()
@@ -331,6 +331,36 @@ def test_device_vector_env_equals_host_vector_env(fog, P):
     # the two engines went through identical states
     H.assert_states_equal(dev.engine.game_state(), host.engine.game_state(), "device vs host vector env")
     host.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_default_numpy_mode_runs_on_the_gym_kernels_and_equals_the_reference_mode():
+    """The default mode (numpy in / numpy out) is the device path plus pinned D2H copies: same values, dtypes and
+    shapes as the numpy_reference mode, step by step."""
+    kw = dict(board_width=10, board_height=10, max_players=3, max_turns=25, seed=11, board_pool=32)
+    ref = V.GeneralsVecEnv(40, numpy_reference=True, **kw)
+    fast = V.GeneralsVecEnv(40, **kw)
+    assert fast._via_kernels and not ref._via_kernels
+    ro, ri = ref.reset()
+    fo, fi = fast.reset()
+    rng = np.random.default_rng(4)
+    for k in range(80):
+        assert isinstance(fo, np.ndarray) and fo.dtype == ro.dtype and fo.shape == ro.shape and np.array_equal(fo.view(np.uint32), ro.view(np.uint32)), k
+        for f in ri:
+            if f == "player_id":
+                continue
+            a, b = np.asarray(fi[f]), np.asarray(ri[f])
+            assert a.dtype == b.dtype and np.array_equal(a, b), (k, f)
+        mask = ri["valid_actions_mask"]
+        acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in mask])
+        if k % 4 == 1:
+            acts[:5] = [int(np.flatnonzero(~m)[3]) for m in mask[:5]]
+        ro, rr, rt, ru, ri = ref.step(acts)
+        fo, fr, ft, fu, fi = fast.step(acts)
+        for a, b in ((fr, rr), (ft, rt), (fu, ru)):
+            a, b = np.asarray(a), np.asarray(b)
+            assert a.dtype == b.dtype and np.array_equal(a, b), k
+    ref.close(); fast.close()
 
 
 @pytest.mark.gpu
