@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--pool", type=int, default=4096)
     ap.add_argument("--gather-envs", type=int, default=4096,
                     help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4]: env i gets a 10x10 / 15x15 / 20x20 board with 2 + i%%3 players in one padded batch "
+                         "(a parity-test configuration, not the bench line)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the record-gather choreography even at world size 1: "
                          "exercises the N>1 code path (side stream, events, experience records, decode) on a single GPU")
@@ -257,8 +260,17 @@ def main():
     W, H, P = args.width, args.height, args.players
     B, total_envs, scaling = shard_plan(args, world, rank)
     eng = g.VecEngine(B, W, H, P, fog_of_war=bool(args.fog), device=local_rank, auto_reset=True, stream=stream.cuda_stream)
-    eng.reset_generated(args.seed * 1000003 + rank)
-    eng.build_board_pool(args.pool, args.seed * 7919 + rank)
+    if args.mixed:
+        import numpy as np
+        side = np.array([10, 15, 20], np.int32)
+        ws, ps = side[np.arange(B) % 3], (2 + np.arange(B) % 3).astype(np.int32)
+        ws, ps = np.minimum(ws, min(W, H)), np.minimum(ps, P)
+        eng.reset_generated(args.seed * 1000003 + rank, ws, ws, ps)
+        pw, pp = side[np.arange(args.pool) % 3], (2 + np.arange(args.pool) % 3).astype(np.int32)
+        eng.build_board_pool(args.pool, args.seed * 7919 + rank, np.minimum(pw, min(W, H)), np.minimum(pw, min(W, H)), np.minimum(pp, P))
+    else:
+        eng.reset_generated(args.seed * 1000003 + rank)
+        eng.build_board_pool(args.pool, args.seed * 7919 + rank)
     seed = args.seed
 
     rgs, side, slab_free = None, None, None
@@ -362,6 +374,8 @@ def main():
                 traffic = None
         mode_txt = (f"{total_envs} boards sharded over {n} GPU(s) ({B} on rank 0; strong scaling)" if scaling == "strong"
                     else f"{B} boards/GPU (weak scaling)")
+        if args.mixed:
+            mode_txt += " MIXED 10x10/15x15/20x20 boards with 2-4 players padded to"
         out = {
             "metric": "env steps/sec (whole node), 20x20 4P fog-on; state bit-exact vs the C restatement of the Go engine "
                       "(the reference's own test vectors pass on both)",

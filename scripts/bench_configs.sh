@@ -11,4 +11,5 @@ run --envs-per-gpu 4096 --width 10 --height 10 --players 2 --fog 0
 run --envs-per-gpu 32768
 run --envs-per-gpu 65536 --width 25 --height 25 --players 4
 run --envs-per-gpu 32768 --width 32 --height 32 --players 8
+run --envs-per-gpu 98304 --mixed
 cat gpurun_out/bench_configs.txt
