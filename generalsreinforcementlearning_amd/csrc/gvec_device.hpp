@@ -74,7 +74,7 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 constexpr int HDR_DW = 24;
 enum : int {
   H_TURN = 0,     // GameState.Turn
-  H_DIMS = 1,     // W | H<<8 | P<<16 | flags<<24   (flags: bit0 Engine.gameOver, bit1 FogOfWarEnabled, bit2 wide armies)
+  H_DIMS = 1,     // W | H<<8 | P<<16 | flags<<24   (flags: HF_* below)
   H_STATUS = 2,   // alive bits | last err<<16
   H_EPISODE = 3,  // re-deal counter (auto-reset)
   H_ARMYCNT = 4,  // [8] Player.ArmyCount
@@ -86,6 +86,13 @@ enum : int {
 };
 constexpr uint32_t HF_DONE = 1u, HF_FOG = 2u, HF_WIDE = 4u;
 constexpr uint32_t HF_SETUP = 8u;  // transient: imported with init, performInitialSetup still to run (setup_kernel clears it)
+// Bookkeeping of the turn engine (never part of the exported state; all three absent = the general paths):
+constexpr uint32_t HF_SYNC = 16u;        // the player stats are exactly what a stats pass over the current lists and armies yields
+                                         // (set by every pass, cleared by an aborted turn and by every state import): the next
+                                         // pass may add the turn's deltas to ArmyCount instead of summing the board
+constexpr uint32_t HF_VSMALL = 32u;      // VisibilityChangedTiles holds at most one tile per player (no turnover since it was cleared)
+constexpr uint32_t HF_FEWSPECIAL = 64u;  // 2*P + generals + cities <= N/5 (a function of the board): without growth or turnover a
+                                         // turn's ChangedTiles cannot reach the full-pass threshold
 
 // plane order inside the planes block; the planes from GEN on never change after a board is imported
 template <int MAXP>
@@ -313,6 +320,12 @@ struct Board {
     ok[1] = dn1(notm) & ncolL;  // target (x+1, y)
     ok[2] = dnW(notm);          // target (x, y+1)
     ok[3] = up1(notm) & ncol0;  // target (x-1, y)
+  }
+  // the header flags that are functions of the board, and "nothing is known" for the turn engine's bookkeeping
+  // flags: wherever a board is imported or modified from outside
+  __device__ __forceinline__ void static_flags() {
+    const int special = (int)wave_sum((uint32_t)__builtin_popcount(gen | city));
+    hflags = (hflags & ~(HF_SYNC | HF_VSMALL | HF_FEWSPECIAL)) | ((2 * P + special <= N / 5) ? HF_FEWSPECIAL : 0u);
   }
   // Tile.Army > 1 as a flat plane
   __device__ __forceinline__ void refresh_gt1() {

@@ -209,7 +209,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
       // the agent's input: the legal-move planes of the resident state, rebuilt from the stored gt1 plane
       // (7 vector instructions; re-reading the 832-byte masks the previous launch wrote would cost more)
       b.template legal_planes<false>(m);
-      const uint32_t mine = (GVEC_PROFILE_SKIP & 1) ? 0u : agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+      uint32_t mine = (GVEC_PROFILE_SKIP & 1) ? 0u : agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+      if (GVEC_PROFILE_DUP & 64) { b.opaque(); b.template legal_planes<false>(m); }
+      if (GVEC_PROFILE_DUP & 1) {
+        b.opaque();
+#pragma unroll
+        for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(m[0][d]));
+        const uint32_t again = agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+        asm volatile("" : : "v"(again));
+      }
       av = agent_actvec<MAXP, NSLOT>(b, mine, A.invalid_permille > 0);
       if (A.actions_out) {
         uint32_t alo, ahi;
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     bool aborted;
     err = b.turn_step(av, A, aborted);
     if (!(GVEC_PROFILE_SKIP & 32)) b.refresh_gt1();
+    if (GVEC_PROFILE_DUP & 32) { b.opaque(); b.refresh_gt1(); }
     b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
-  if (emit && (changed || !(A.flags & KF_LMVALID))) {
+  if (!(GVEC_PROFILE_SKIP & 64) && emit && (changed || !(A.flags & KF_LMVALID))) {
     b.template legal_planes<false>(m);
     b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, FD, A.pstride);
   }
@@ -900,6 +909,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   }
   // the planes that are functions of the board: rebuilt on every import (the type planes may have changed)
   b.targets();
+  b.static_flags();
   b.refresh_gt1();
   if (A.init) b.hflags |= HF_SETUP;  // performInitialSetup runs in setup_kernel, on the turn engine's layout
   b.store_army(army);
@@ -1032,6 +1042,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) b.army[s] = (64 * s + lane < b.N) ? b.army[s] : 0;
     b.targets();
+    b.static_flags();
     b.refresh_gt1();
     b.store_army(army_ref<NSLOT>(A.army16, A.army32, env));
     b.store_hdr(A.hdr + (size_t)env * HDR_DW, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);

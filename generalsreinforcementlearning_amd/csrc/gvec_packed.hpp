@@ -25,6 +25,11 @@
 #ifndef GVEC_PROFILE_SKIP
 #define GVEC_PROFILE_SKIP 0
 #endif
+// -DGVEC_PROFILE_DUP=<bits> runs an idempotent phase TWICE instead (same bits; the game is unchanged, so the counter
+// difference to the plain build is that phase's dynamic cost - skipping a phase changes what the boards do next)
+#ifndef GVEC_PROFILE_DUP
+#define GVEC_PROFILE_DUP 0
+#endif
 // 1: the action phase runs on lanes when no two moves of a turn share a tile (act_vector); 0: always sequential (A/B)
 #ifndef GVEC_ACT_VECTOR
 #define GVEC_ACT_VECTOR 1
@@ -92,9 +97,9 @@ struct PBoard {
   static constexpr int ROWL = 64 / PPR;               // lanes per row
   static constexpr int NR = (MAXP + PPR - 1) / PPR;   // registers per plane kind
   static constexpr bool FULL_ROWS = (2 * NSLOT >= ROWL);  // a plane can fill its row: shifts must not cross rows
-  // LDS scratch of the vector action phase: three ROWL-dword tile bitmaps (candidate tiles, changed, captured) and one
-  // 64-dword image per packed ownership register (the bits captures set)
-  static constexpr int ACT_SCRATCH_DW = 3 * ROWL + 64 * NR;
+  // LDS scratch of the vector action phase: three ROWL-dword tile bitmaps (candidate tiles, changed, captured), one
+  // 64-dword image per packed ownership register (the bits captures set) and 8 dwords of army lost per defending player
+  static constexpr int ACT_SCRATCH_DW = 3 * ROWL + 64 * NR + 8;
 
   uint32_t own[NR], lst[NR], vis[NR];         // packed: row r of register k = player k*PPR + r
   uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
@@ -109,6 +114,11 @@ struct PBoard {
   // every army stays below 2^23 until the board is stored (true for one turn from a NARROW load): the
   // masked sums may then use full-rate 24-bit multiply-adds.  Set by the kernel, never by load_*.
   bool small = false;
+  // what one turn hands from its action and production phases to the end-of-turn stats pass (update_stats)
+  int32_t move_delta = 0;      // lane p: change of player p's listed army through this turn's moves (act_vector)
+  uint32_t prod_mask = 0u;     // the tiles production raised, replicated in every row ...
+  int32_t prod_rate = 0;       // ... by this much each (prod_uniform), else the delta path is off
+  bool prod_uniform = false, grow = false;
 
   static __device__ __forceinline__ int col() { return lane_id() & (ROWL - 1); }
   static __device__ __forceinline__ int row() { return lane_id() / ROWL; }
@@ -214,6 +224,11 @@ struct PBoard {
     asm volatile("" : "+v"(ncolL));
 #pragma unroll
     for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(ok[d]));
+  }
+  // profiling builds: makes the state opaque to the optimiser between two runs of the same phase
+  __device__ __forceinline__ void opaque() {
+    land();
+    asm volatile("" : "+s"(turn), "+s"(alive), "+s"(hflags));
   }
   __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
@@ -344,9 +359,17 @@ struct PBoard {
     return __builtin_amdgcn_ubfe(bperm(((row_base + (lane >> 5)) << 2) + 8 * s, plane), (uint32_t)(lane & 31), 1u);
   }
   static __device__ __forceinline__ uint32_t replicate_row0(uint32_t plane) { return bperm(col() << 2, plane); }
-  // popcount of a replicated plane (row 0 only)
+  // popcount of a replicated plane: row 0's lanes summed (the scan's zero fill keeps other rows out)
   __device__ __forceinline__ int count_shared(uint32_t plane) const {
-    return (int)wave_sum((lane_id() < ROWL) ? (uint32_t)__builtin_popcount(plane) : 0u);
+    return (int)rdlane(row_scan_add<ROWL>((uint32_t)__builtin_popcount(plane)), ROWL - 1);
+  }
+  static __device__ __forceinline__ bool any_bit(uint32_t plane) { return __builtin_amdgcn_ballot_w64(plane != 0u) != 0ull; }
+  // OwnedTiles == board ownership for every player (no owned-but-unlisted tile, H6)
+  __device__ __forceinline__ bool lists_match() const {
+    uint32_t d = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) d |= lst[k] ^ own[k];
+    return !any_bit(d);
   }
   // Tile.Army > 1 as a replicated flat plane: the ballot of slot s is dwords 2s, 2s+1 of the bit string
   // (written into row 0 with v_writelane: 2*NSLOT <= ROWL), one ds_bpermute copies row 0 into every row
@@ -362,10 +385,19 @@ struct PBoard {
   }
 
   // ---- Engine.updateFogOfWarOptimized (visibility_optimized.go:16-97) ---------------------------------
-  __device__ __forceinline__ void update_fog() {
+  // matched: lists_match() holds (the caller needs it too)
+  __device__ __forceinline__ void update_fog(bool matched = false) {
     if (!(hflags & HF_FOG)) return;  // :17-19
-    const int nv = count_shared(vch);
-    if (turn == 0 || nv > N / 10) {  // :22-26 full: clear, then 3x3 around every listed tile of alive players (:33-53)
+    bool full, none;
+    if ((hflags & HF_VSMALL) && turn > 0 && P <= N / 10) {  // at most P tiles in V: below the threshold whatever they are
+      full = false;
+      none = !any_bit(vch);
+    } else {
+      const int nv = count_shared(vch);
+      full = turn == 0 || nv > N / 10;
+      none = nv == 0;
+    }
+    if (full) {  // :22-26 full: clear, then 3x3 around every listed tile of alive players (:33-53)
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const uint32_t d = dil3(lst[k]);  // all players of the register at once
@@ -373,13 +405,17 @@ struct PBoard {
       }
       return;
     }
-    if (nv == 0) return;  // incremental update over an empty set is the identity
+    if (none) return;  // incremental update over an empty set is the identity
     // :56-97 affected = board owners within 5x5 of V (:100-116); clear all players in 3x3 of V
-    // (:132-150); re-light affected, alive players from their lists (:85-94)
-    const uint32_t near3 = dil3(vch), near5 = dil3(near3), clr = ~near3;
+    // (:132-150); re-light affected, alive players from their lists (:85-94).
+    // "p owns a tile within 5x5 of V" <=> the 3x3 hull of p's tiles meets the 3x3 hull of V (two steps of a
+    // king's walk on the board); with lists == ownership that hull is the one the re-lighting needs anyway.
+    const uint32_t near3 = dil3(vch), clr = ~near3;
+    const uint32_t near5 = matched ? 0u : dil3(near3);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const unsigned long long hit = __builtin_amdgcn_ballot_w64((own[k] & near5) != 0u);
+      const uint32_t d = dil3(lst[k]);
+      const unsigned long long hit = __builtin_amdgcn_ballot_w64((matched ? (d & near3) : (own[k] & near5)) != 0u);
       uint32_t relight = 0u;  // per-player bit set, wave-uniform
 #pragma unroll
       for (int r = 0; r < PPR; ++r) {
@@ -387,7 +423,6 @@ struct PBoard {
         relight |= ((hit >> (r * ROWL)) & rowbits) ? (1u << (k * PPR + r)) : 0u;
       }
       relight &= alive;
-      const uint32_t d = dil3(lst[k]);
       vis[k] = (vis[k] & clr) | (lane_flag(relight, k) ? d : 0u);
     }
   }
@@ -436,33 +471,67 @@ struct PBoard {
   }
 
   // ---- Engine.updatePlayerStats (stats.go:8-144) ------------------------------------------------------
-  __device__ __forceinline__ void update_stats() {
-    const int nc = count_shared(chg);
-    if (nc == 0 && turn > 0) return;             // :10-14
-    const bool full = turn == 0 || nc > N / 5;  // :20-21
-#pragma unroll
-    for (int k = 0; k < NR; ++k) lst[k] = full ? own[k] : (own[k] & (lst[k] | chg));  // :33-49 / :90-130
-    int32_t acc[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) acc[p] = 0;
-    if (small) {  // bit * army + acc in one full-rate v_mad_u32_u24
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p)
-          acc[p] = (int32_t)mad24((uint32_t)army[s], gather(lst[p / PPR], s, (p % PPR) * ROWL), (uint32_t)acc[p]);
-      }
+  // end_of_turn: the turn's one pass, no elimination before it - ChangedTiles is then at most two tiles per player plus
+  //   what production raised, which outside growth turns is a subset of the generals and cities (HF_FEWSPECIAL bounds it).
+  // delta: additionally the stats were exact when the turn began (HF_SYNC), lists equalled ownership, and the moves
+  //   went through act_vector (or nobody moved): ArmyCount' = ArmyCount + move_delta + rate * |produced tiles the player
+  //   holds now| - what the sums over the new lists give, without visiting the armies.  Lists that did not change keep
+  //   Alive / GeneralIdx as the last pass left them.
+  __device__ __forceinline__ void update_stats(bool end_of_turn = false, bool delta = false) {
+    bool full;
+    if (end_of_turn && !grow && (hflags & HF_FEWSPECIAL) && turn > 0) {
+      if (!any_bit(chg)) return;  // :10-14
+      full = false;               // |C| <= 2P + generals + cities <= N/5
     } else {
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
-      }
+      const int nc = count_shared(chg);
+      if (nc == 0 && turn > 0) return;       // :10-14
+      full = turn == 0 || nc > N / 5;        // :20-21
     }
-    {  // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
-      const int lane = lane_id();
+    uint32_t moved = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t nl = full ? own[k] : (own[k] & (lst[k] | chg));  // :33-49 / :90-130
+      moved |= nl ^ lst[k];
+      lst[k] = nl;
+    }
+    const int lane = lane_id();
+    if (delta && !full && prod_uniform) {
+      uint32_t add = dpp0<0x114>((lane < MAXP) ? (uint32_t)move_delta : 0u);  // row_shr:4: lane p -> header lane H_ARMYCNT + p
+      static_assert(H_ARMYCNT == 4 && MAXP <= 8, "row_shr:4 lands lanes 0..MAXP-1 on the ArmyCount lanes");
+      if (prod_rate != 0) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const uint32_t sc = row_scan_add<ROWL>((uint32_t)__builtin_popcount(prod_mask & lst[k]));  // row totals in the rows' last lanes
+          const int p = lane - H_ARMYCNT;
+          const uint32_t got = bperm((((p & (PPR - 1)) * ROWL) + ROWL - 1) << 2, sc);
+          add += (p >= 0 && p < MAXP && p / PPR == k) ? __umul24(got, (uint32_t)prod_rate) : 0u;  // rates < 2^24 (gvec_create), got <= 1024
+        }
+      }
+      hv += (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? add : 0u;
+      hflags |= HF_SYNC;
+      if (!any_bit(moved)) return;  // same lists, same generals on them
+    } else {
+      int32_t acc[MAXP];
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) acc[p] = 0;
+      if (small) {  // bit * army + acc in one full-rate v_mad_u32_u24
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+          for (int p = 0; p < MAXP; ++p)
+            acc[p] = (int32_t)mad24((uint32_t)army[s], gather(lst[p / PPR], s, (p % PPR) * ROWL), (uint32_t)acc[p]);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+          for (int p = 0; p < MAXP; ++p) acc[p] += army[s] & gather_mask(lst[p / PPR], s, (p % PPR) * ROWL);
+        }
+      }
+      // Player.ArmyCount: header lanes H_ARMYCNT .. H_ARMYCNT+MAXP-1
       const uint32_t tot = multi_sum(acc);
       hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
+      hflags |= HF_SYNC;
     }
     alive = 0u;
 #pragma unroll
@@ -494,7 +563,6 @@ struct PBoard {
   // (a scalar `%` by a run-time value compiles to v_cvt / v_rcp / v_mul / v_cvt + 20 scalar instructions).
   // q = mulhi(turn, magic) is floor(turn / interval) or one more while turn * interval < 2^32; beyond that the plain `%`.
   __device__ __forceinline__ void production(int pg, int pc, int pn, int interval, uint32_t interval_magic) {
-    bool grow;
     if ((uint32_t)turn < 0x10000u && (uint32_t)interval < 0x10000u) {
       const uint32_t q = __umulhi((uint32_t)turn, interval_magic);  // wave-uniform operands: s_mul_hi_u32
       int32_t r = turn - (int32_t)(q * (uint32_t)interval);
@@ -513,8 +581,11 @@ struct PBoard {
     if (grow && pn > 0) mn = listed_alive & ~(gen | city | mtn) & valid;  // wave-uniform: one turn in `interval`
     chg |= mg | mc | mn;  // :59-61 (prod > 0 only)
     const int an = (grow && pn > 0) ? pn : pc;
-    if (pg == pc && pc == an) {  // one rate for every producing tile: one gather per slot
-      const uint32_t m = mg | mc | mn;
+    prod_uniform = pg == pc && pc == an;
+    prod_mask = mg | mc | mn;
+    prod_rate = pg;
+    if (prod_uniform) {  // one rate for every producing tile: one gather per slot
+      const uint32_t m = prod_mask;
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) army[s] = (int32_t)mad24(gather(m, s), (uint32_t)pg, (uint32_t)army[s]);  // rates < 2^24 (gvec_create)
     } else {
@@ -624,6 +695,7 @@ struct PBoard {
     uint32_t* s_chg = lscr + ROWL;
     uint32_t* s_cap = lscr + 2 * ROWL;
     uint32_t* s_own = lscr + 3 * ROWL;
+    uint32_t* s_loss = lscr + 3 * ROWL + 64 * NR;
 #pragma unroll
     for (int i = 0; i < (ACT_SCRATCH_DW + 63) / 64; ++i)
       if (64 * i + lane < ACT_SCRATCH_DW) lscr[64 * i + lane] = 0u;
@@ -647,15 +719,20 @@ struct PBoard {
     // pre-turn facts of my move
     const int32_t fa = larmy[ft], ta = larmy[tt];
     const int myrow = (lane % PPR) * ROWL;
-    uint32_t w_ft = 0u, w_tt = 0u;  // my own ownership row at the source / target dword
+    uint32_t w_ft = 0u;  // my own ownership row at the source dword
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const uint32_t g = bperm((myrow + fcol) << 2, own[k]), h = bperm((myrow + tcol) << 2, own[k]);
+      const uint32_t g = bperm((myrow + fcol) << 2, own[k]);
       w_ft = (lane / PPR == k) ? g : w_ft;
-      w_tt = (lane / PPR == k) ? h : w_tt;
+    }
+    uint32_t owner_bits = 0u;  // bit q: player q owns my target tile (pre-turn; none: neutral)
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+      const uint32_t g = bperm((((q % PPR) * ROWL) + tcol) << 2, own[q / PPR]);
+      owner_bits |= ((g >> (tt & 31)) & 1u) << q;
     }
     const bool own_ft = ((w_ft >> (ft & 31)) & 1u) != 0u;
-    const bool mine_tt = ((w_tt >> (tt & 31)) & 1u) != 0u;
+    const bool mine_tt = ((owner_bits >> lane) & 1u) != 0u;  // lane < MAXP wherever it matters (cand)
     const bool mtn_tt = ((bperm(tcol << 2, mtn) >> (tt & 31)) & 1u) != 0u;
     const bool gen_tt = ((bperm(tcol << 2, gen) >> (tt & 31)) & 1u) != 0u;
     // MoveAction.Validate, the state-dependent half, in the reference's order (action.go:82-98)
@@ -683,27 +760,21 @@ struct PBoard {
       atomicOr(&s_cap[tcol], tbit);                            // action_processor.go:84-86
       atomicOr(&s_own[64 * (lane / PPR) + myrow + tcol], tbit);  // :69-82 the tile is mine now
     }
+    // What the move does to the armies on LISTED tiles when lists equal ownership (update_stats' delta path): on my own
+    // tile nothing moves out of my hands; anywhere else the fight burns `loss` on both sides - mine (-n at the source,
+    // + n - ta at a captured target) and the previous owner's (the tile's ta with the tile, or n off its army).
+    const int32_t loss = (ok && !mine_tt) ? (capture ? ta : n) : 0;
+    if (loss != 0 && owner_bits != 0u) atomicAdd(&s_loss[__builtin_ctz(owner_bits)], (uint32_t)loss);
     wave_lds_fence();
+    move_delta = -(loss + (int32_t)s_loss[lane & 7]);
     const uint32_t capbits = s_cap[col()];
     chg |= s_chg[col()];
     vch |= capbits;
-    uint32_t own_before[NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      own_before[k] = own[k];
-      own[k] = (own[k] & ~capbits) | s_own[64 * k + lane];
-    }
+    for (int k = 0; k < NR; ++k) own[k] = (own[k] & ~capbits) | s_own[64 * k + lane];
     // core.ProcessCaptures (movement.go:100-118): captured generals with a previous owner, in PlayerID order
     unsigned long long el = __builtin_amdgcn_ballot_w64(capture && gen_tt);
-    uint32_t owner_bits = 0u;  // bit q: player q owned the captured tile (pre-turn; none: neutral general, no order)
-    if (el) {                  // rare: only now is the previous owner needed
-#pragma unroll
-      for (int q = 0; q < MAXP; ++q) {
-        const uint32_t g = bperm((((q % PPR) * ROWL) + tcol) << 2, own_before[q / PPR]);
-        owner_bits |= ((g >> (tt & 31)) & 1u) << q;
-      }
-      el = __builtin_amdgcn_ballot_w64(capture && gen_tt && owner_bits != 0u);
-    }
+    if (el) el = __builtin_amdgcn_ballot_w64(capture && gen_tt && owner_bits != 0u);  // a neutral general: no order
     while (el) {
       const int p = (int)__builtin_ctzll(el);
       el &= el - 1ull;
@@ -742,6 +813,7 @@ struct PBoard {
       hdr_set(H_GIDX + v, 0xFFFFFFFFu);  // :141 GeneralIdx = -1
       chg |= tiles;                      // :133-134
       vch |= tiles;
+      hflags &= ~HF_VSMALL;
       alive &= ~(1u << v);  // :140
     }
   }
@@ -756,9 +828,14 @@ struct PBoard {
   __device__ __forceinline__ uint32_t turn_step(const ActVec& av, const StepArgs& A, bool& aborted) {
     aborted = false;
     turn++;  // initializeTurn :124-135
-    if (!(GVEC_PROFILE_SKIP & 2)) update_fog();
+    const bool matched = lists_match();
+    if (!(GVEC_PROFILE_SKIP & 2)) update_fog(matched);
+    if (GVEC_PROFILE_DUP & 2) { opaque(); update_fog(matched); }
     chg = 0u;
     vch = 0u;
+    hflags |= HF_VSMALL;  // the moves add one captured tile per player at most; a turnover clears the flag
+    bool delta = matched && (hflags & HF_SYNC) != 0u;
+    move_delta = 0;
     uint32_t first_err = 0u, elim_seen = 0u;
     uint64_t orders = 0ull;
     int n_orders = 0;
@@ -766,8 +843,10 @@ struct PBoard {
     const unsigned long long present = __builtin_amdgcn_ballot_w64((av.meta & 16u) != 0u && lane_id() < P);
     if (present && !(GVEC_PROFILE_SKIP & 4)) {  // a turn where nobody moves touches no army
       army_to_lds();
-      if (!(GVEC_ACT_VECTOR && lscr && act_vector(av, first_err, orders, n_orders, elim_seen)))
+      if (!(GVEC_ACT_VECTOR && lscr && act_vector(av, first_err, orders, n_orders, elim_seen))) {
         act_chain<0>(av, first_err, orders, n_orders, elim_seen);
+        delta = false;  // the sequential path keeps no account of the armies it moved
+      }
       army_from_lds();
     }
     if (n_orders > 0) {  // engine.go:101-109
@@ -775,11 +854,13 @@ struct PBoard {
       update_stats();
     }
     if (first_err) {  // engine.go:111-113 -> turn_processor.go:55-57: production, stats, game-over skipped (H5)
+      if (n_orders == 0) hflags &= ~HF_SYNC;  // armies moved and no pass followed
       aborted = true;
       return first_err;
     }
     if (!(GVEC_PROFILE_SKIP & 8)) production(A.prod_general, A.prod_city, A.prod_normal, A.interval, A.interval_magic);  // :60
-    if (!(GVEC_PROFILE_SKIP & 16)) update_stats();                                                       // :65,170-179
+    if (!(GVEC_PROFILE_SKIP & 16)) update_stats(n_orders == 0, delta && n_orders == 0);                  // :65,170-179
+    if (GVEC_PROFILE_DUP & 16) { opaque(); update_stats(n_orders == 0, false); }
     check_game_over();
     return 0u;
   }
@@ -791,7 +872,7 @@ struct PBoard {
     vch = 0u;
 #pragma unroll
     for (int k = 0; k < NR; ++k) vis[k] = 0u;
-    hflags &= ~HF_DONE;
+    hflags = (hflags & ~HF_DONE) | HF_VSMALL;
     update_stats();  // Turn == 0 => full
     update_fog();    // Turn == 0 => full
     check_game_over();

@@ -1,0 +1,105 @@
+// Microbenchmark (not product code): the round-2 step kernel's HBM access pattern without its compute.
+// One wavefront per env: header 96 B (read + write), planes 25 x 52 B read as 7 packed-register loads (lane 16r+i =
+// plane 4k+r, dword i) and 15 x 52 B written back as 4 stores, armies as u16 pairs (224 dwords read + written),
+// legal masks 4 x 208 B written.  Flags try the same bytes out of place (ping-pong buffers) and with plain stores.
+//   hipcc --offload-arch=gfx950 -O3 -o copy_pattern2 copy_pattern2.hip && ./copy_pattern2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+struct Args { uint32_t *hdr, *rows, *army, *mask, *hdr2, *rows2, *army2; int n; };
+
+template <bool NT> __device__ __forceinline__ void st(uint32_t* p, uint32_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// F bits: 1 out of place (stores go to the second buffer set), 2 non-temporal stores, 4 no mask stores, 8 loads only,
+// 16 stores only, 32 skip the stores of 2 of the 4 plane registers (quiet turn), 64 army stores only for lanes < 16 (partial lines)
+template <int F, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k(Args a) {
+  const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63;
+  if (env >= a.n) return;
+  constexpr bool NT = (F & 2) != 0;
+  const uint32_t* hdr = a.hdr + (size_t)env * 24;
+  const uint32_t* rows = a.rows + (size_t)env * 328;
+  const uint32_t* army = a.army + (size_t)env * 224;
+  uint32_t* hdr_o = ((F & 1) ? a.hdr2 : a.hdr) + (size_t)env * 24;
+  uint32_t* rows_o = ((F & 1) ? a.rows2 : a.rows) + (size_t)env * 328;
+  uint32_t* army_o = ((F & 1) ? a.army2 : a.army) + (size_t)env * 224;
+  uint32_t* mask = a.mask + (size_t)env * 208;
+  const int r = lane >> 4, i = lane & 15;
+  uint32_t h = 0, p[7], q[4];
+  if constexpr (!(F & 16)) {
+    h = lane < 24 ? hdr[lane] : 0u;
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) p[k2] = (i < 13 && 4 * k2 + r < 25) ? rows[(4 * k2 + r) * 13 + i] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = (64 * j + lane < 224) ? army[64 * j + lane] : 0u;
+  } else {
+    h = lane;
+    for (int k2 = 0; k2 < 7; ++k2) p[k2] = lane * k2;
+    for (int j = 0; j < 4; ++j) q[j] = lane + j;
+  }
+  if constexpr (F & 8) {
+    uint32_t acc = h;
+    for (int k2 = 0; k2 < 7; ++k2) acc += p[k2];
+    for (int j = 0; j < 4; ++j) acc += q[j];
+    if (acc == 0x12345678u) a.hdr2[0] = acc;
+  } else {
+    if (lane < 24) st<NT>(hdr_o + lane, h + 1u);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      if ((F & 32) && (k2 == 0 || k2 == 2)) continue;
+      if (i < 13 && 4 * k2 + r < 15) st<NT>(rows_o + (4 * k2 + r) * 13 + i, p[k2] ^ p[6]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (64 * j + lane < 224 && (!(F & 64) || (lane & 15) < 4)) st<NT>(army_o + 64 * j + lane, q[j] + 1u);
+    if constexpr (!(F & 4)) {
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) if (lane < 52) st<NT>(mask + 52 * k2 + lane, p[k2] + q[k2]);
+    }
+  }
+}
+
+template <int F, int WAVES>
+void run(const Args& a, const char* what) {
+  double rd = 96 + 1300 + 896, wr = 96 + 780 + 896 + 832;
+  if (F & 4) wr -= 832;
+  if (F & 32) wr -= 416;
+  if (F & 64) wr -= 896 * 0.75;
+  if (F & 8) wr = 0;
+  if (F & 16) rd = 0;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipEventRecord(e0);
+    for (int it = 0; it < 40; ++it) hipLaunchKernelGGL((k<F, WAVES>), dim3(a.n / 4), dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double us = best / 40 * 1e3;
+  printf("%-66s %7.1f us  %5.0f GB/s  (%4.0f B read + %4.0f B written per env)\n", what, us, a.n * (rd + wr) / us / 1e3, rd, wr);
+}
+
+int main() {
+  const int n = 262144;
+  Args a; a.n = n;
+  uint32_t** bufs[] = {&a.hdr, &a.rows, &a.army, &a.mask, &a.hdr2, &a.rows2, &a.army2};
+  const size_t sz[] = {96, 1312, 896, 832, 96, 1312, 896};
+  for (int b = 0; b < 7; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
+  run<2, 8>(a, "in place, non-temporal stores (the step kernel's pattern)");
+  run<0, 8>(a, "in place, plain stores");
+  run<3, 8>(a, "out of place (ping-pong), non-temporal stores");
+  run<1, 8>(a, "out of place, plain stores");
+  run<2, 4>(a, "in place, nt, 4 waves/SIMD");
+  run<2, 2>(a, "in place, nt, 2 waves/SIMD");
+  run<2 | 8, 8>(a, "loads only");
+  run<2 | 16, 8>(a, "stores only, nt");
+  run<16, 8>(a, "stores only, plain");
+  run<2 | 4, 8>(a, "in place, nt, no mask stores");
+  run<2 | 32, 8>(a, "in place, nt, two plane registers not stored (quiet turn)");
+  run<2 | 64, 8>(a, "in place, nt, army stores on a quarter of the lanes (partial lines)");
+  return 0;
+}

@@ -127,7 +127,8 @@ def test_record_slab_carries_wide_envs_and_rejects_foreign_headers(g):
     sa, sb = a.game_state(), b.game_state()
     for f in sa:
         assert np.array_equal(sa[f], sb[f]), f
-    assert np.array_equal(_header_flags(a), _header_flags(b))
+    # game over / fog / wide armies travel; the turn engine's bookkeeping flags (HF_SYNC, HF_VSMALL) restart on import
+    assert np.array_equal(_header_flags(a) & 7, _header_flags(b) & 7)
     assert np.array_equal(a.legal_action_mask_bits(), b.legal_action_mask_bits())
     # a slab from an engine with other limits (or a corrupted one) is refused on the device, env by env
     hdr = buf[: B * 96].view(torch.int32).reshape(B, 24)
