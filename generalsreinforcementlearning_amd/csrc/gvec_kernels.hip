@@ -124,11 +124,12 @@ __device__ __forceinline__ void load_turn(BT& b, const uint32_t* hdr, const uint
     b.decode_hdr_scalar(hdr);   // SMEM: in flight with the vector loads above
     b.land();
     b.land_scalars();
+    b.spread_shared();
     b.load_army_wide_if_flagged(army);
   } else {
     b.load_hdr(hdr);
     b.load_army(army);
-    b.load_planes(rows, fd, zeros);
+    b.template load_planes<false>(rows, fd, zeros);
   }
 }
 
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     bool aborted;
     err = b.turn_step(av, A, aborted);
     if (!(GVEC_PROFILE_SKIP & 32)) b.refresh_gt1();
-    if (GVEC_PROFILE_DUP & 32) { b.opaque(); b.refresh_gt1(); }
+    if (GVEC_PROFILE_DUP & 32) { b.opaque_v(); b.refresh_gt1(); }
     b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);

@@ -105,6 +105,9 @@ struct PBoard {
   uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
   uint32_t valid, ncol0, ncolL, ok[4];        // replicated constant planes (see Board)
   uint32_t rowbit[NR];                        // 1 << (the player this lane holds in register k)
+  static constexpr int NSHARED = PL::COUNT - PL::CHG;           // the 13 shared planes, CHG .. OK[3], contiguous in the block
+  static constexpr int NSR = (NSHARED + PPR - 1) / PPR;         // ... loaded PPR at a time, like the packed ones
+  uint32_t shp[NSR];                          // in flight between load_planes and spread_shared: row r of shp[k] = shared plane k*PPR + r
   int32_t army[NSLOT];                        // tile domain, as in Board
   uint32_t hv;
   int32_t* larmy;                             // LDS shadow of the armies during the action phase: tile t at larmy[t]
@@ -213,22 +216,27 @@ struct PBoard {
       asm volatile("" : "+v"(lst[k]));
       asm volatile("" : "+v"(vis[k]));
     }
-    asm volatile("" : "+v"(chg));
-    asm volatile("" : "+v"(vch));
-    asm volatile("" : "+v"(gt1));
-    asm volatile("" : "+v"(gen));
-    asm volatile("" : "+v"(city));
-    asm volatile("" : "+v"(mtn));
-    asm volatile("" : "+v"(valid));
-    asm volatile("" : "+v"(ncol0));
-    asm volatile("" : "+v"(ncolL));
 #pragma unroll
-    for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(ok[d]));
+    for (int k = 0; k < NSR; ++k) asm volatile("" : "+v"(shp[k]));
   }
   // profiling builds: makes the state opaque to the optimiser between two runs of the same phase
   __device__ __forceinline__ void opaque() {
-    land();
+    opaque_v();
     asm volatile("" : "+s"(turn), "+s"(alive), "+s"(hflags));
+  }
+  __device__ __forceinline__ void opaque_v() {
+    asm volatile("" : "+v"(hv));
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) asm volatile("" : "+v"(army[s]));
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      asm volatile("" : "+v"(own[k]));
+      asm volatile("" : "+v"(lst[k]));
+      asm volatile("" : "+v"(vis[k]));
+    }
+    asm volatile("" : "+v"(chg));
+    asm volatile("" : "+v"(vch));
+    asm volatile("" : "+v"(gt1));
   }
   __device__ __forceinline__ void hdr_set(int k, uint32_t v) { hv = (uint32_t)gvec_llvm_writelane((int)v, k, (int)hv); }
   __device__ __forceinline__ uint32_t hdr_get(int k) const { return rdlane(hv, k); }
@@ -239,32 +247,61 @@ struct PBoard {
     if (lane_id() < HDR_DW) hdr_env[lane_id()] = hv;
   }
 
-  // ---- planes: one load per packed register (PPR planes at once), shared planes replicated ------------
-  // Lanes that hold no dword of the bit string (column >= fd, or a row without a player) must read as zero.
-  // They are pointed at `zeros` - a block of at least row_dw zero dwords - so every plane is ONE load with an
-  // immediate offset and no select on the data (16 selects per board otherwise).
+  // ---- planes: one load per PPR planes (row r of a register = plane base + r) ----------------------------
+  // Lanes that hold no dword of the bit string (column >= fd, or a row without a plane) must read as zero.
+  // They are pointed at `zeros` - a block of at least row_dw zero dwords - so every load is ONE instruction with an
+  // immediate offset and no select on the data.  The shared planes come in PPR at a time as well (a load per shared
+  // plane with every row reading the same dwords is 13 vector-memory instructions instead of 4, and the memory
+  // pipeline, not the bytes, then sets the pace: scripts/microbench/copy_pattern2.hip) and are spread over the rows
+  // afterwards, one ds_bpermute each (spread_shared).  PACK = false: the shared planes one load each, every row reading
+  // the same dwords - for the kernels that load a board once and then play many turns on it (no spread_shared, and
+  // no registers held for it).
+  template <bool PACK = true>
   __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd, const uint32_t* zeros) {
     const bool in = col() < fd;
-    const uint32_t* gs = in ? rows_env + col() : zeros;  // shared: every row reads the same dwords
+    const uint32_t* lane_base = rows_env + (row() * fd + col());
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const bool on = in && (k * PPR + row() < MAXP);
-      const uint32_t* gp = on ? rows_env + (row() * fd + col()) : zeros;  // packed: plane (base + row), dword col
+      const uint32_t* gp = (in && (k * PPR + row() < MAXP)) ? lane_base : zeros;  // packed: plane (base + row), dword col
       own[k] = ld_stream(gp + (PL::OWN + k * PPR) * fd);
       lst[k] = ld_stream(gp + (PL::LST + k * PPR) * fd);
       vis[k] = ld_stream(gp + (PL::VIS + k * PPR) * fd);
     }
-    chg = ld_stream(gs + PL::CHG * fd);
-    vch = ld_stream(gs + PL::VCH * fd);
-    gt1 = ld_stream(gs + PL::GT1 * fd);
-    gen = ld_stream(gs + PL::GEN * fd);
-    city = ld_stream(gs + PL::CITY * fd);
-    mtn = ld_stream(gs + PL::MTN * fd);
-    valid = ld_stream(gs + PL::VALID * fd);
-    ncol0 = ld_stream(gs + PL::NCOL0 * fd);
-    ncolL = ld_stream(gs + PL::NCOLL * fd);
+    if constexpr (PACK) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) ok[d] = ld_stream(gs + (PL::OK + d) * fd);
+      for (int k = 0; k < NSR; ++k) {
+        const uint32_t* gp = (in && (k * PPR + row() < NSHARED)) ? lane_base : zeros;
+        shp[k] = ld_stream(gp + (PL::CHG + k * PPR) * fd);
+      }
+    } else {
+      const uint32_t* gs = in ? rows_env + col() : zeros;
+      chg = ld_stream(gs + PL::CHG * fd);
+      vch = ld_stream(gs + PL::VCH * fd);
+      gt1 = ld_stream(gs + PL::GT1 * fd);
+      gen = ld_stream(gs + PL::GEN * fd);
+      city = ld_stream(gs + PL::CITY * fd);
+      mtn = ld_stream(gs + PL::MTN * fd);
+      valid = ld_stream(gs + PL::VALID * fd);
+      ncol0 = ld_stream(gs + PL::NCOL0 * fd);
+      ncolL = ld_stream(gs + PL::NCOLL * fd);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) ok[d] = ld_stream(gs + (PL::OK + d) * fd);
+    }
+  }
+  // shared plane j (CHG + j), replicated in every row
+  __device__ __forceinline__ uint32_t shared_plane(int j) const { return bperm((((j % PPR) * ROWL) + col()) << 2, shp[j / PPR]); }
+  __device__ __forceinline__ void spread_shared() {
+    chg = shared_plane(PL::CHG - PL::CHG);
+    vch = shared_plane(PL::VCH - PL::CHG);
+    gt1 = shared_plane(PL::GT1 - PL::CHG);
+    gen = shared_plane(PL::GEN - PL::CHG);
+    city = shared_plane(PL::CITY - PL::CHG);
+    mtn = shared_plane(PL::MTN - PL::CHG);
+    valid = shared_plane(PL::VALID - PL::CHG);
+    ncol0 = shared_plane(PL::NCOL0 - PL::CHG);
+    ncolL = shared_plane(PL::NCOLL - PL::CHG);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ok[d] = shared_plane(PL::OK + d - PL::CHG);
   }
   // The planes from GEN on change only when the env is re-dealt (with_types).
   __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
@@ -278,12 +315,15 @@ struct PBoard {
         st_stream<GVEC_NT_PLANE>(gp + (PL::VIS + k * PPR) * fd, vis[k]);
       }
     }
+    static_assert(PL::VCH == PL::CHG + 1 && PL::GT1 == PL::CHG + 2, "the three mutable shared planes are stored as rows of one register");
+#pragma unroll
+    for (int k = 0; k * PPR < 3; ++k) {
+      const int j = k * PPR + row();
+      if (in && j < 3) st_stream<GVEC_NT_PLANE>(gp + (PL::CHG + k * PPR) * fd, j == 0 ? chg : (j == 1 ? vch : gt1));
+    }
     const int lane = lane_id();
     if (lane < fd) {  // lanes 0..fd-1 are row 0, columns 0..fd-1 (fd <= ROWL)
       uint32_t* g = rows_env + lane;
-      st_stream<GVEC_NT_PLANE>(g + PL::CHG * fd, chg);
-      st_stream<GVEC_NT_PLANE>(g + PL::VCH * fd, vch);
-      st_stream<GVEC_NT_PLANE>(g + PL::GT1 * fd, gt1);
       if (with_types) {
         g[PL::GEN * fd] = gen;
         g[PL::CITY * fd] = city;

@@ -7,13 +7,15 @@
 #include <cstdio>
 #include <cstdint>
 
-struct Args { uint32_t *hdr, *rows, *army, *mask, *hdr2, *rows2, *army2; int n; };
+struct Args { uint32_t *hdr, *rows, *army, *mask, *hdr2, *rows2, *army2, *zeros; int* err; int n; };
 
 template <bool NT> __device__ __forceinline__ void st(uint32_t* p, uint32_t v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
 // F bits: 1 out of place (stores go to the second buffer set), 2 non-temporal stores, 4 no mask stores, 8 loads only,
+// 128 planes loaded the way the step kernel does (3 packed + 13 row-replicated loads, idle lanes pointed at a zero block),
+// 256 + four header fields through the scalar cache, 512 + one int per env (err), 1024 + 9 KB of LDS per workgroup
 // 16 stores only, 32 skip the stores of 2 of the 4 plane registers (quiet turn), 64 army stores only for lanes < 16 (partial lines)
 template <int F, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k(Args a) {
@@ -30,10 +32,28 @@ __global__ __launch_bounds__(256, WAVES) void k(Args a) {
   uint32_t* mask = a.mask + (size_t)env * 208;
   const int r = lane >> 4, i = lane & 15;
   uint32_t h = 0, p[7], q[4];
+  __shared__ uint32_t lds_pad[(F & 1024) ? 2304 : 1];
+  if constexpr ((F & 1024) != 0) lds_pad[threadIdx.x] = threadIdx.x;
   if constexpr (!(F & 16)) {
     h = lane < 24 ? hdr[lane] : 0u;
+    if constexpr ((F & 128) != 0) {
+      const bool in = i < 13;
+      const uint32_t* gs = in ? rows + i : a.zeros;
+      const uint32_t* gp = in ? rows + r * 13 + i : a.zeros;
+      p[0] = gp[0 * 13]; p[1] = gp[4 * 13]; p[2] = gp[8 * 13];
+      uint32_t sh[13];
+#pragma unroll
+      for (int k2 = 0; k2 < 13; ++k2) sh[k2] = gs[(12 + k2) * 13];
+      p[3] = sh[0] ^ sh[1] ^ sh[2]; p[4] = sh[3] + sh[4] + sh[5]; p[5] = sh[6] ^ sh[7] ^ sh[8]; p[6] = sh[9] + sh[10] + sh[11] + sh[12];
+    } else {
 #pragma unroll
     for (int k2 = 0; k2 < 7; ++k2) p[k2] = (i < 13 && 4 * k2 + r < 25) ? rows[(4 * k2 + r) * 13 + i] : 0u;
+    }
+    if constexpr ((F & 256) != 0) {
+      typedef const __attribute__((address_space(4))) uint32_t* kptr;
+      kptr kk = (kptr)hdr;
+      h += kk[0] + kk[1] + kk[2] + kk[20];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) q[j] = (64 * j + lane < 224) ? army[64 * j + lane] : 0u;
   } else {
@@ -47,6 +67,8 @@ __global__ __launch_bounds__(256, WAVES) void k(Args a) {
     for (int j = 0; j < 4; ++j) acc += q[j];
     if (acc == 0x12345678u) a.hdr2[0] = acc;
   } else {
+    if constexpr ((F & 1024) != 0) h += lds_pad[(threadIdx.x + 64) & 255];
+    if constexpr ((F & 512) != 0) if (lane == 0) a.err[env] = (int)h;
     if (lane < 24) st<NT>(hdr_o + lane, h + 1u);
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
@@ -86,10 +108,15 @@ void run(const Args& a, const char* what) {
 int main() {
   const int n = 262144;
   Args a; a.n = n;
-  uint32_t** bufs[] = {&a.hdr, &a.rows, &a.army, &a.mask, &a.hdr2, &a.rows2, &a.army2};
-  const size_t sz[] = {96, 1312, 896, 832, 96, 1312, 896};
-  for (int b = 0; b < 7; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
+  uint32_t** bufs[] = {&a.hdr, &a.rows, &a.army, &a.mask, &a.hdr2, &a.rows2, &a.army2, &a.zeros, (uint32_t**)&a.err};
+  const size_t sz[] = {96, 1312, 896, 832, 96, 1312, 896, 1, 4};
+  for (int b = 0; b < 9; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
   run<2, 8>(a, "in place, non-temporal stores (the step kernel's pattern)");
+  run<2 | 128, 8>(a, "  + planes as 3 packed + 13 replicated loads, zero block");
+  run<2 | 128 | 256, 8>(a, "  + header fields through the scalar cache");
+  run<2 | 128 | 256 | 512, 8>(a, "  + err store");
+  run<2 | 128 | 256 | 512 | 1024, 8>(a, "  + 9 KB of LDS per workgroup");
+  run<2 | 4 | 128 | 256 | 512 | 1024, 8>(a, "  ... without mask stores (the frozen-board step)");
   run<0, 8>(a, "in place, plain stores");
   run<3, 8>(a, "out of place (ping-pong), non-temporal stores");
   run<1, 8>(a, "out of place, plain stores");
