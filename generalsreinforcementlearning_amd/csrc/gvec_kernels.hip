@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (!(GVEC_PROFILE_SKIP & 64) && emit && (changed || !(A.flags & KF_LMVALID))) {
     b.template legal_planes<false>(m);
-    b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, FD, A.pstride);
+    b.store_masks_staged(m, A.legal + (size_t)env * A.pstride * A.mask_dw, FD, A.pstride);
   }
 }
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
-  b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
+  b.store_masks_staged(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
 }
 
 // legal masks / agent actions of the resident state (no turn is played)

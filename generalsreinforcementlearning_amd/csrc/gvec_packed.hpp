@@ -953,6 +953,36 @@ struct PBoard {
       }
     }
   }
+  // The same bytes through the LDS army shadow (idle once the action phase is over): store_masks' instructions each
+  // write one direction of every player - pieces of fd dwords, 4*fd dwords apart - and partial-line writes from four
+  // instructions cost the memory pipeline 11 % of the whole step (scripts/microbench/copy_pattern2.hip).  Staged, the
+  // env's mask block leaves as whole 16-byte chunks of consecutive lanes: one store instruction at 20x20 4P.
+  // Needs larmy (NSLOT*64 dwords >= pstride*4*fd for MAXP <= 8); legal_env is 16-byte aligned (4*fd dwords per player).
+  __device__ __forceinline__ void store_masks_staged(const uint32_t (&m)[NR][4], uint32_t* legal_env, int fd, int pstride) const {
+    static_assert(MAXP <= 8, "the army shadow holds the mask block");
+    uint32_t* stage = reinterpret_cast<uint32_t*>(larmy);
+    const bool in = col() < fd;
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int p = lane_player(k);
+      if (in && p < pstride && p < MAXP) {
+        uint32_t* g = stage + p * (4 * fd) + col();
+#pragma unroll
+        for (int d = 0; d < 4; ++d) g[d * fd] = m[k][d];
+      }
+    }
+    wave_lds_fence();
+    const int chunks = pstride * fd;  // 16-byte chunks: pstride * 4 * fd dwords
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(stage);
+    u32x4* g4 = reinterpret_cast<u32x4*>(legal_env);
+    for (int i = lane_id(); i < chunks; i += 64) {
+      const u32x4 v = s4[i];
+      if constexpr ((GVEC_NT & GVEC_NT_MASK) != 0) __builtin_nontemporal_store(v, g4 + i);
+      else g4[i] = v;
+    }
+  }
 };
 
 }  // namespace gvec

@@ -16,18 +16,23 @@ template <bool NT> __device__ __forceinline__ void st(uint32_t* p, uint32_t v) {
 // F bits: 1 out of place (stores go to the second buffer set), 2 non-temporal stores, 4 no mask stores, 8 loads only,
 // 128 planes loaded the way the step kernel does (3 packed + 13 row-replicated loads, idle lanes pointed at a zero block),
 // 256 + four header fields through the scalar cache, 512 + one int per env (err), 1024 + 9 KB of LDS per workgroup
+// 2048 XCD-aware env order (blocks b, b+8, ... walk one contiguous eighth), 4096 mask stores the way the step kernel
+// issues them (one direction of all four players per instruction: four 52-byte pieces 208 bytes apart),
+// 8192 header and planes blocks padded to whole 128-byte lines
 // 16 stores only, 32 skip the stores of 2 of the 4 plane registers (quiet turn), 64 army stores only for lanes < 16 (partial lines)
 template <int F, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k(Args a) {
-  const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int blk = (F & 2048) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int env = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (env >= a.n) return;
   constexpr bool NT = (F & 2) != 0;
-  const uint32_t* hdr = a.hdr + (size_t)env * 24;
-  const uint32_t* rows = a.rows + (size_t)env * 328;
+  constexpr int HS = (F & 8192) ? 32 : 24, RS = (F & 8192) ? 352 : 328;
+  const uint32_t* hdr = a.hdr + (size_t)env * HS;
+  const uint32_t* rows = a.rows + (size_t)env * RS;
   const uint32_t* army = a.army + (size_t)env * 224;
-  uint32_t* hdr_o = ((F & 1) ? a.hdr2 : a.hdr) + (size_t)env * 24;
-  uint32_t* rows_o = ((F & 1) ? a.rows2 : a.rows) + (size_t)env * 328;
+  uint32_t* hdr_o = ((F & 1) ? a.hdr2 : a.hdr) + (size_t)env * HS;
+  uint32_t* rows_o = ((F & 1) ? a.rows2 : a.rows) + (size_t)env * RS;
   uint32_t* army_o = ((F & 1) ? a.army2 : a.army) + (size_t)env * 224;
   uint32_t* mask = a.mask + (size_t)env * 208;
   const int r = lane >> 4, i = lane & 15;
@@ -79,7 +84,10 @@ __global__ __launch_bounds__(256, WAVES) void k(Args a) {
     for (int j = 0; j < 4; ++j) if (64 * j + lane < 224 && (!(F & 64) || (lane & 15) < 4)) st<NT>(army_o + 64 * j + lane, q[j] + 1u);
     if constexpr (!(F & 4)) {
 #pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) if (lane < 52) st<NT>(mask + 52 * k2 + lane, p[k2] + q[k2]);
+      for (int k2 = 0; k2 < 4; ++k2) {
+        if constexpr ((F & 4096) != 0) { if (i < 13) st<NT>(mask + r * 52 + k2 * 13 + i, p[k2] + q[k2]); }
+        else if (lane < 52) st<NT>(mask + 52 * k2 + lane, p[k2] + q[k2]);
+      }
     }
   }
 }
@@ -109,7 +117,7 @@ int main() {
   const int n = 262144;
   Args a; a.n = n;
   uint32_t** bufs[] = {&a.hdr, &a.rows, &a.army, &a.mask, &a.hdr2, &a.rows2, &a.army2, &a.zeros, (uint32_t**)&a.err};
-  const size_t sz[] = {96, 1312, 896, 832, 96, 1312, 896, 1, 4};
+  const size_t sz[] = {128, 1408, 896, 832, 128, 1408, 896, 1, 4};
   for (int b = 0; b < 9; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
   run<2, 8>(a, "in place, non-temporal stores (the step kernel's pattern)");
   run<2 | 128, 8>(a, "  + planes as 3 packed + 13 replicated loads, zero block");
@@ -117,6 +125,12 @@ int main() {
   run<2 | 128 | 256 | 512, 8>(a, "  + err store");
   run<2 | 128 | 256 | 512 | 1024, 8>(a, "  + 9 KB of LDS per workgroup");
   run<2 | 4 | 128 | 256 | 512 | 1024, 8>(a, "  ... without mask stores (the frozen-board step)");
+  run<2 | 2048, 8>(a, "the first line, XCD-aware env order");
+  run<2 | 128 | 256 | 512 | 1024 | 2048, 8>(a, "step-kernel-like, XCD-aware env order");
+  run<2 | 4096, 8>(a, "the first line, mask stores in four 52-byte pieces per instruction");
+  run<2 | 2048 | 4096, 8>(a, "  ... with XCD-aware env order");
+  run<2 | 8192, 8>(a, "the first line, header and planes blocks padded to 128-byte lines");
+  run<2 | 2048 | 8192, 8>(a, "  ... with XCD-aware env order");
   run<0, 8>(a, "in place, plain stores");
   run<3, 8>(a, "out of place (ping-pong), non-temporal stores");
   run<1, 8>(a, "out of place, plain stores");

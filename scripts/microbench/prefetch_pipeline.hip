@@ -92,6 +92,25 @@ __global__ __launch_bounds__(256, 8) void piped(Args a) {
   }
 }
 
+// C: one board per wave like A, but the loads go through LDS (4 global_load_lds instructions, then ds_reads)
+__global__ __launch_bounds__(256, 8) void staged(Args a) {
+  __shared__ uint32_t stage_all[4][STAGE_DW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+  if (env >= a.n) return;
+  uint32_t* stage = stage_all[wave];
+  const int r = lane >> 4, i = lane & 15;
+  prefetch(a, env, stage, lane);
+  uint32_t p[7], q[4];
+  const uint32_t h = lane < 24 ? stage[lane] : 0u;
+#pragma unroll
+  for (int k2 = 0; k2 < 7; ++k2) p[k2] = (i < 13 && 4 * k2 + r < 25) ? stage[32 + (4 * k2 + r) * 13 + i] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = (64 * j + lane < 224) ? stage[32 + 328 + 64 * j + lane] : 0u;
+  const uint32_t x = fake_turn(h, p, q, a.work);
+  store_board(a, env, lane, h, p, q, x);
+}
+
 template <typename K>
 void run(K kern, const Args& a, int grid, const char* what) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -113,9 +132,10 @@ int main() {
   uint32_t** bufs[] = {&a.hdr, &a.rows, &a.army, &a.mask};
   const size_t sz[] = {96, 1312, 896, 832};
   for (int b = 0; b < 4; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
-  for (int work : {0, 50, 100, 150, 200}) {
+  for (int work : {0, 100}) {
     a.work = work;
     run(plain, a, n / 4, "A one board per wave");
+    run(staged, a, n / 4, "C one board per wave, loads through LDS (4 global_load_lds)");
     run(piped, a, 2048, "B persistent, next board prefetched into LDS (2048 workgroups)");
     run(piped, a, 4096, "B persistent, prefetched (4096 workgroups)");
     run(piped, a, 16384, "B 4 boards per wave, prefetched (16384 workgroups)");
