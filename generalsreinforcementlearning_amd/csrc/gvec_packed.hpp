@@ -260,20 +260,31 @@ struct PBoard {
   __device__ __forceinline__ void load_planes(const uint32_t* rows_env, int fd, const uint32_t* zeros) {
     const bool in = col() < fd;
     const uint32_t* lane_base = rows_env + (row() * fd + col());
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const uint32_t* gp = (in && (k * PPR + row() < MAXP)) ? lane_base : zeros;  // packed: plane (base + row), dword col
-      own[k] = ld_stream(gp + (PL::OWN + k * PPR) * fd);
-      lst[k] = ld_stream(gp + (PL::LST + k * PPR) * fd);
-      vis[k] = ld_stream(gp + (PL::VIS + k * PPR) * fd);
-    }
     if constexpr (PACK) {
+      // the per-turn kernel: lanes without a dword do not load at all (every wave of the chip reading the one zero
+      // block makes its cache lines a hot spot of the L2 channels they live in)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        own[k] = lst[k] = vis[k] = 0u;
+        if (in && (k * PPR + row() < MAXP)) {
+          own[k] = ld_stream(lane_base + (PL::OWN + k * PPR) * fd);
+          lst[k] = ld_stream(lane_base + (PL::LST + k * PPR) * fd);
+          vis[k] = ld_stream(lane_base + (PL::VIS + k * PPR) * fd);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NSR; ++k) {
-        const uint32_t* gp = (in && (k * PPR + row() < NSHARED)) ? lane_base : zeros;
-        shp[k] = ld_stream(gp + (PL::CHG + k * PPR) * fd);
+        shp[k] = 0u;
+        if (in && (k * PPR + row() < NSHARED)) shp[k] = ld_stream(lane_base + (PL::CHG + k * PPR) * fd);
       }
     } else {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const uint32_t* gp = (in && (k * PPR + row() < MAXP)) ? lane_base : zeros;  // packed: plane (base + row), dword col
+        own[k] = ld_stream(gp + (PL::OWN + k * PPR) * fd);
+        lst[k] = ld_stream(gp + (PL::LST + k * PPR) * fd);
+        vis[k] = ld_stream(gp + (PL::VIS + k * PPR) * fd);
+      }
       const uint32_t* gs = in ? rows_env + col() : zeros;
       chg = ld_stream(gs + PL::CHG * fd);
       vch = ld_stream(gs + PL::VCH * fd);
