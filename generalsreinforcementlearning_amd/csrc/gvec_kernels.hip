@@ -242,9 +242,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
   }
-  b.store_army(army_env);  // picks the narrow / wide form: before the header, which records it
+  b.store_army_staged(army_env);  // picks the narrow / wide form: before the header, which records it
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
-  b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, types_dirty);
+  if (types_dirty) b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, true);
+  else b.store_planes_staged(A.rows + (size_t)env * ROW_DW, FD);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
   if (!(GVEC_PROFILE_SKIP & 64) && emit && (changed || !(A.flags & KF_LMVALID))) {
     b.template legal_planes<false>(m);

@@ -964,6 +964,66 @@ struct PBoard {
       }
     }
   }
+  // ---- stores of the per-turn kernel: through the LDS army shadow, as whole 16-byte chunks of consecutive lanes ----
+  // The memory pipeline, not the bytes, sets the step kernel's pace (scripts/microbench/copy_pattern2.hip): a block
+  // that leaves as ONE wide store instruction is cheaper than the same bytes in four narrow ones.  The shadow is idle
+  // once the action phase is over; every routine fences before it overwrites what the previous one staged.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  template <int CLASS>
+  __device__ __forceinline__ void flush_stage(uint32_t* dst, int dwords) const {  // dst 16-byte aligned
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(larmy);
+    u32x4* g4 = reinterpret_cast<u32x4*>(dst);
+    const int chunks = dwords >> 2;
+    for (int i = lane_id(); i < chunks; i += 64) {
+      const u32x4 v = s4[i];
+      if constexpr ((GVEC_NT & CLASS) != 0) __builtin_nontemporal_store(v, g4 + i);
+      else g4[i] = v;
+    }
+    const int tail = dwords & 3, l = lane_id();
+    if (l < tail) st_stream<CLASS>(dst + 4 * chunks + l, reinterpret_cast<const uint32_t*>(larmy)[4 * chunks + l]);
+  }
+  // the planes that change in a turn (OWN .. GT1: contiguous in the block)
+  __device__ __forceinline__ void store_planes_staged(uint32_t* rows_env, int fd) const {
+    uint32_t* stage = reinterpret_cast<uint32_t*>(larmy);
+    const bool in = col() < fd;
+    uint32_t* g = stage + row() * fd + col();
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      if (in && (k * PPR + row() < MAXP)) {
+        g[(PL::OWN + k * PPR) * fd] = own[k];
+        g[(PL::LST + k * PPR) * fd] = lst[k];
+        g[(PL::VIS + k * PPR) * fd] = vis[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k * PPR < 3; ++k) {
+      const int j = k * PPR + row();
+      if (in && j < 3) g[(PL::CHG + k * PPR) * fd] = j == 0 ? chg : (j == 1 ? vch : gt1);
+    }
+    wave_lds_fence();
+    flush_stage<GVEC_NT_PLANE>(rows_env, PL::MUTABLE * fd);
+  }
+  // narrow armies (the caller has checked army_fits_narrow): the block's layout is army_store_narrow's
+  __device__ __forceinline__ void store_army_narrow_staged(uint32_t* n) const {
+    uint32_t* stage = reinterpret_cast<uint32_t*>(larmy);
+    const int lane = lane_id();
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NSLOT / 2; ++k) stage[64 * k + lane] = (uint32_t)army[2 * k] | ((uint32_t)army[2 * k + 1] << 16);
+    if constexpr ((NSLOT & 1) != 0) reinterpret_cast<uint16_t*>(stage + 64 * (NSLOT / 2))[lane] = (uint16_t)army[NSLOT - 1];
+    wave_lds_fence();
+    flush_stage<GVEC_NT_ARMY>(n, NSLOT * 32);
+  }
+  __device__ __forceinline__ void store_army_staged(const ArmyRef& a) {  // sets / clears HF_WIDE: call BEFORE store_hdr
+    if (army_fits_narrow<NSLOT>(army)) {
+      hflags &= ~HF_WIDE;
+      store_army_narrow_staged(a.n);
+    } else {
+      hflags |= HF_WIDE;
+      army_store_wide<NSLOT>(army, a.w);
+    }
+  }
   // The same bytes through the LDS army shadow (idle once the action phase is over): store_masks' instructions each
   // write one direction of every player - pieces of fd dwords, 4*fd dwords apart - and partial-line writes from four
   // instructions cost the memory pipeline 11 % of the whole step (scripts/microbench/copy_pattern2.hip).  Staged, the
@@ -984,15 +1044,7 @@ struct PBoard {
       }
     }
     wave_lds_fence();
-    const int chunks = pstride * fd;  // 16-byte chunks: pstride * 4 * fd dwords
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* s4 = reinterpret_cast<const u32x4*>(stage);
-    u32x4* g4 = reinterpret_cast<u32x4*>(legal_env);
-    for (int i = lane_id(); i < chunks; i += 64) {
-      const u32x4 v = s4[i];
-      if constexpr ((GVEC_NT & GVEC_NT_MASK) != 0) __builtin_nontemporal_store(v, g4 + i);
-      else g4[i] = v;
-    }
+    flush_stage<GVEC_NT_MASK>(legal_env, pstride * 4 * fd);
   }
 };
 
