@@ -53,18 +53,39 @@ extern "C" __device__ int gvec_llvm_writelane(int value, int lane, int vdst_in) 
 #define GVEC_NT_MASK 2
 #define GVEC_NT_PLANE 4
 #define GVEC_NT_ARMY 8
+// 1: the streaming stores carry `sc1 nt` - written through, the line dropped from the XCD's L2 - instead of `nt` alone.
+// scripts/microbench/copy_pattern2.hip, the step kernel's bytes as 16-byte-per-lane stores: nt 255 us, nt sc1 196 us,
+// sc1 alone 290 us, no bits 280 us per 262,144 boards.  The compiler has no spelling for the pair short of `volatile`
+// (which also serialises the stores), hence the inline assembly; nothing ever waits for these stores, and the one
+// wait state a wide store's data registers need before they are rewritten is in the string.
+#ifndef GVEC_SC1
+#define GVEC_SC1 1
+#endif
 
 namespace gvec {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
   if constexpr ((GVEC_NT & 1) != 0) return __builtin_nontemporal_load(p);
   return *p;
 }
+__device__ __forceinline__ void st_through(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_through(uint16_t* p, uint16_t v) {
+  asm volatile("global_store_short %0, %1, off sc1 nt" : : "v"(p), "v"((uint32_t)v) : "memory");
+}
+__device__ __forceinline__ void st_through(u32x4* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+}
 template <int CLASS, typename T>
 __device__ __forceinline__ void st_stream(T* p, T v) {
-  if constexpr ((GVEC_NT & CLASS) != 0) __builtin_nontemporal_store(v, p);
-  else *p = v;
+  if constexpr ((GVEC_NT & CLASS) != 0) {
+    if constexpr (GVEC_SC1 != 0) st_through(p, v);
+    else __builtin_nontemporal_store(v, p);
+  } else {
+    *p = v;
+  }
 }
 
 // ---- resident record layout (per env) -------------------------------------------------

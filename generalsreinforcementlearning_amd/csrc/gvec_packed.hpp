@@ -968,16 +968,13 @@ struct PBoard {
   // The memory pipeline, not the bytes, sets the step kernel's pace (scripts/microbench/copy_pattern2.hip): a block
   // that leaves as ONE wide store instruction is cheaper than the same bytes in four narrow ones.  The shadow is idle
   // once the action phase is over; every routine fences before it overwrites what the previous one staged.
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   template <int CLASS>
   __device__ __forceinline__ void flush_stage(uint32_t* dst, int dwords) const {  // dst 16-byte aligned
     const u32x4* s4 = reinterpret_cast<const u32x4*>(larmy);
     u32x4* g4 = reinterpret_cast<u32x4*>(dst);
     const int chunks = dwords >> 2;
     for (int i = lane_id(); i < chunks; i += 64) {
-      const u32x4 v = s4[i];
-      if constexpr ((GVEC_NT & CLASS) != 0) __builtin_nontemporal_store(v, g4 + i);
-      else g4[i] = v;
+      st_stream<CLASS>(g4 + i, s4[i]);
     }
     const int tail = dwords & 3, l = lane_id();
     if (l < tail) st_stream<CLASS>(dst + 4 * chunks + l, reinterpret_cast<const uint32_t*>(larmy)[4 * chunks + l]);

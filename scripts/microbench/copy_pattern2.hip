@@ -22,7 +22,11 @@ template <bool NT> __device__ __forceinline__ void st(uint32_t* p, uint32_t v) {
 // 16 stores only, 32 skip the stores of 2 of the 4 plane registers (quiet turn), 64 army stores only for lanes < 16 (partial lines)
 template <int F, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k(Args a) {
-  const int blk = (F & 2048) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  // 16384: blocks walk the envs with a large odd stride (concurrent workgroups far apart in memory);
+  // 32768: neighbouring blocks 64 envs apart inside 1,024-env tiles (the 8 XCDs interleave at 16-block granularity)
+  int blk = (F & 2048) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if constexpr ((F & 16384) != 0) blk = (int)(((unsigned long long)blockIdx.x * 40503ull) % gridDim.x);
+  if constexpr ((F & 32768) != 0) blk = (int)((blockIdx.x & ~255u) | ((blockIdx.x & 15u) << 4) | ((blockIdx.x >> 4) & 15u));
   const int env = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (env >= a.n) return;
@@ -92,6 +96,68 @@ __global__ __launch_bounds__(256, WAVES) void k(Args a) {
   }
 }
 
+// the same bytes as 16-byte-per-lane accesses of consecutive lanes (LOADS: also the loads; else the loads as in k<2>)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// cache-policy bits on a 16-byte store: 0 nt (the builtin), 1 none, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1, 6 sc0
+template <int POL> __device__ __forceinline__ void stx4(u32x4* p, u32x4 v) {
+  if constexpr (POL == 0) __builtin_nontemporal_store(v, p);
+  else if constexpr (POL == 1) *p = v;
+  else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+  else if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+  else if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off nt sc1" :: "v"(p), "v"(v) : "memory");
+  else if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+template <bool LOADS, int POL = 0>
+__global__ __launch_bounds__(256, 8) void wide(Args a) {
+  const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63;
+  if (env >= a.n) return;
+  u32x4* hdr = reinterpret_cast<u32x4*>(a.hdr + (size_t)env * 24);
+  u32x4* rows = reinterpret_cast<u32x4*>(a.rows + (size_t)env * 328);
+  u32x4* army = reinterpret_cast<u32x4*>(a.army + (size_t)env * 224);
+  u32x4* mask = reinterpret_cast<u32x4*>(a.mask + (size_t)env * 208);
+  u32x4 h = {0, 0, 0, 0}, r0 = h, r1 = h, q = h;
+  if constexpr (LOADS) {
+    if (lane < 6) h = hdr[lane];
+    r0 = rows[lane];
+    if (lane < 18) r1 = rows[64 + lane];
+    if (lane < 56) q = army[lane];
+  } else {
+    const uint32_t* hd = a.hdr + (size_t)env * 24;
+    const uint32_t* rw = a.rows + (size_t)env * 328;
+    const uint32_t* ar = a.army + (size_t)env * 224;
+    const int r = lane >> 4, i = lane & 15;
+    h.x = lane < 24 ? hd[lane] : 0u;
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) r0[k2 & 3] += (i < 13 && 4 * k2 + r < 25) ? rw[(4 * k2 + r) * 13 + i] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = (64 * j + lane < 224) ? ar[64 * j + lane] : 0u;
+    r1 = r0;
+  }
+  h.x += 1u; r0.y ^= r1.x; q.z += 1u;
+  if constexpr (LOADS) { if (lane < 6) __builtin_nontemporal_store(h, hdr + lane); }
+  else if (lane < 24) __builtin_nontemporal_store(h.x, a.hdr + (size_t)env * 24 + lane);
+  if (lane < 48) stx4<POL>(rows + lane, r0);
+  if (lane < 3) __builtin_nontemporal_store(r1.x, a.rows + (size_t)env * 328 + 192 + lane);
+  if (lane < 56) stx4<POL>(army + lane, q);
+  if (lane < 52) stx4<POL>(mask + lane, r0 + q);
+}
+template <bool LOADS, int POL = 0>
+void run_wide(const Args& a, const char* what) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipEventRecord(e0);
+    for (int it = 0; it < 40; ++it) hipLaunchKernelGGL((wide<LOADS, POL>), dim3(a.n / 4), dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double us = best / 40 * 1e3;
+  printf("%-66s %7.1f us  %5.0f GB/s  (%4.0f B read + %4.0f B written per env)\n", what, us, a.n * 4896.0 / us / 1e3, 2292.0, 2604.0);
+}
+
 template <int F, int WAVES>
 void run(const Args& a, const char* what) {
   double rd = 96 + 1300 + 896, wr = 96 + 780 + 896 + 832;
@@ -120,6 +186,14 @@ int main() {
   const size_t sz[] = {128, 1408, 896, 832, 128, 1408, 896, 1, 4};
   for (int b = 0; b < 9; ++b) { (void)hipMalloc(bufs[b], n * sz[b]); (void)hipMemset(*bufs[b], 0, n * sz[b]); }
   run<2, 8>(a, "in place, non-temporal stores (the step kernel's pattern)");
+  run_wide<false>(a, "stores as 16-byte-per-lane chunks (the step kernel now), dword loads");
+  run_wide<true>(a, "loads AND stores as 16-byte-per-lane chunks");
+  run_wide<false, 1>(a, "wide stores, no policy bits");
+  run_wide<false, 2>(a, "wide stores, sc1");
+  run_wide<false, 3>(a, "wide stores, sc0 sc1");
+  run_wide<false, 4>(a, "wide stores, nt sc1");
+  run_wide<false, 5>(a, "wide stores, nt sc0 sc1");
+  run_wide<false, 6>(a, "wide stores, sc0");
   run<2 | 128, 8>(a, "  + planes as 3 packed + 13 replicated loads, zero block");
   run<2 | 128 | 256, 8>(a, "  + header fields through the scalar cache");
   run<2 | 128 | 256 | 512, 8>(a, "  + err store");
@@ -131,6 +205,8 @@ int main() {
   run<2 | 2048 | 4096, 8>(a, "  ... with XCD-aware env order");
   run<2 | 8192, 8>(a, "the first line, header and planes blocks padded to 128-byte lines");
   run<2 | 2048 | 8192, 8>(a, "  ... with XCD-aware env order");
+  run<2 | 16384, 8>(a, "the first line, blocks walk the envs with a large odd stride");
+  run<2 | 32768, 8>(a, "the first line, 16x16 transposed block order inside 1,024-env tiles");
   run<0, 8>(a, "in place, plain stores");
   run<3, 8>(a, "out of place (ping-pong), non-temporal stores");
   run<1, 8>(a, "out of place, plain stores");
