@@ -119,8 +119,8 @@ template <bool EARLY = false, typename BT>
 __device__ __forceinline__ void load_turn(BT& b, const uint32_t* hdr, const uint32_t* rows, const ArmyCRef& army, int fd, const uint32_t* zeros) {
   if constexpr (EARLY) {
     b.issue_hdr(hdr);
-    b.load_army_narrow(army);
     b.load_planes(rows, fd, zeros);
+    b.load_army_narrow(army);
     b.decode_hdr_scalar(hdr);   // SMEM: in flight with the vector loads above
     b.land();
     b.land_scalars();
