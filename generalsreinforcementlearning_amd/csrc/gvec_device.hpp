@@ -112,16 +112,21 @@ constexpr uint32_t HF_SYNC = 16u;        // the player stats are exactly what a 
                                          // (set by every pass, cleared by an aborted turn and by every state import): the next
                                          // pass may add the turn's deltas to ArmyCount instead of summing the board
 constexpr uint32_t HF_VSMALL = 32u;      // VisibilityChangedTiles holds at most one tile per player (no turnover since it was cleared)
+constexpr uint32_t HF_LDIFF = 128u;      // some player's OwnedTiles differ from what it owns (H6: after an aborted turn, until a pass heals
+                                         // it): only then are the LST planes of the block authoritative - and read or written at all.
+                                         // Clear: lists == ownership, the stored LST planes are stale.  Kept true by settle_lists().
 constexpr uint32_t HF_FEWSPECIAL = 64u;  // 2*P + generals + cities <= N/5 (a function of the board): without growth or turnover a
                                          // turn's ChangedTiles cannot reach the full-pass threshold
 
-// plane order inside the planes block; the planes from GEN on never change after a board is imported
+// plane order inside the planes block: what every turn rewrites (OWN .. GT1, contiguous), what changes only when a
+// board is imported or re-dealt (GEN .. OK[3]), and last the list planes, which most turns neither read nor write
+// (HF_LDIFF)
 template <int MAXP>
 struct Planes {
-  static constexpr int OWN = 0, LST = MAXP, VIS = 2 * MAXP, CHG = 3 * MAXP, VCH = 3 * MAXP + 1, GT1 = 3 * MAXP + 2,
-                       GEN = 3 * MAXP + 3, CITY = 3 * MAXP + 4, MTN = 3 * MAXP + 5, VALID = 3 * MAXP + 6, NCOL0 = 3 * MAXP + 7,
-                       NCOLL = 3 * MAXP + 8, OK = 3 * MAXP + 9 /* [4]: up, right, down, left */, COUNT = 3 * MAXP + 13,
-                       MUTABLE = 3 * MAXP + 3;
+  static constexpr int OWN = 0, VIS = MAXP, CHG = 2 * MAXP, VCH = 2 * MAXP + 1, GT1 = 2 * MAXP + 2,
+                       GEN = 2 * MAXP + 3, CITY = 2 * MAXP + 4, MTN = 2 * MAXP + 5, VALID = 2 * MAXP + 6, NCOL0 = 2 * MAXP + 7,
+                       NCOLL = 2 * MAXP + 8, OK = 2 * MAXP + 9 /* [4]: up, right, down, left */, LST = 2 * MAXP + 13,
+                       COUNT = 3 * MAXP + 13, MUTABLE = 2 * MAXP + 3, SHARED = 13 /* CHG .. OK[3] */;
 };
 
 constexpr uint32_t KF_AGENT = 1u;      // sample actions on device instead of reading them
@@ -400,11 +405,13 @@ struct Board {
       const uint32_t v = g[plane * fd];
       return on ? v : 0u;
     };
+    const bool listed = (hflags & HF_LDIFF) != 0u;  // needs the header: call after load_hdr
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       own[p] = ld(PL::OWN + p);
-      lst[p] = ld(PL::LST + p);
       vis[p] = ld(PL::VIS + p);
+      lst[p] = own[p];
+      if (listed) lst[p] = ld(PL::LST + p);
     }
     chg = ld(PL::CHG);
     vch = ld(PL::VCH);
@@ -419,16 +426,24 @@ struct Board {
     for (int d = 0; d < 4; ++d) ok[d] = ld(PL::OK + d);
   }
 
-  // The planes from GEN on change only when a board is imported or re-dealt (with_types).
-  __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types) const {
+  // Sets HF_LDIFF to what the lists are: call BEFORE store_hdr (store_planes writes the list planes accordingly).
+  __device__ __forceinline__ void settle_lists() {
+    uint32_t d = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) d |= lst[p] ^ own[p];
+    hflags = wave_any(d != 0u) ? (hflags | HF_LDIFF) : (hflags & ~HF_LDIFF);
+  }
+  // The planes from GEN on change only when a board is imported or re-dealt (with_types).  all_lists: write the list
+  // planes whatever the flag says (a record slab is complete on its own).
+  __device__ __forceinline__ void store_planes(uint32_t* rows_env, int fd, int row_dw, bool with_types, bool all_lists = false) const {
     const int lane = lane_id();
     if (lane < fd) {
       uint32_t* g = rows_env + lane;
 #pragma unroll
       for (int p = 0; p < MAXP; ++p) {
         g[(PL::OWN + p) * fd] = own[p];
-        g[(PL::LST + p) * fd] = lst[p];
         g[(PL::VIS + p) * fd] = vis[p];
+        if (all_lists || (hflags & HF_LDIFF)) g[(PL::LST + p) * fd] = lst[p];
       }
       g[PL::CHG * fd] = chg;
       g[PL::VCH * fd] = vch;
@@ -441,11 +456,10 @@ struct Board {
         g[PL::NCOL0 * fd] = ncol0;
         g[PL::NCOLL * fd] = ncolL;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) g[(PL::OK + d) * fd] = ok[d];
+        for (int d = 0; d < 4; ++d) g[(PL::OK + d) * fd] = ok[d];
       }
     }
-    // the last plane and the block's padding in one store (lanes >= fd write zeros)
-    if (with_types && lane < row_dw - (PL::OK + 3) * fd) rows_env[(PL::OK + 3) * fd + lane] = (lane < fd) ? ok[3] : 0u;
+    if (with_types && lane < row_dw - PL::COUNT * fd) rows_env[PL::COUNT * fd + lane] = 0u;  // the block's padding
   }
 
   // whole 64-tile slots travel both ways (the padding beyond N holds zeros).

@@ -125,6 +125,7 @@ __device__ __forceinline__ void load_turn(BT& b, const uint32_t* hdr, const uint
     b.land();
     b.land_scalars();
     b.spread_shared();
+    b.load_lists(rows, fd);
     b.load_army_wide_if_flagged(army);
   } else {
     b.load_hdr(hdr);
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
     if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
   }
   b.store_army_staged(army_env);  // picks the narrow / wide form: before the header, which records it
+  b.settle_lists();               // ... and so is whether the list planes are stored
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   if (types_dirty) b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, true);
   else b.store_planes_staged(A.rows + (size_t)env * ROW_DW, FD);
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + n_abort);
   b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + n_done);
   b.store_army(army_env);
+  b.settle_lists();
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
   b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   if (A.err && lane == 0) A.err[env] = (int32_t)err;
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void setup_kernel(ImportArgs 
   if (!(b.hflags & HF_SETUP)) return;  // this env's input was rejected: left as it was
   b.hflags &= ~HF_SETUP;
   b.initial_setup();
+  b.settle_lists();
   b.store_hdr(A.hdr + (size_t)env * HDR_DW, 0u);
   b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, false);
 }
@@ -915,6 +919,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void import_kernel(ImportArgs
   b.refresh_gt1();
   if (A.init) b.hflags |= HF_SETUP;  // performInitialSetup runs in setup_kernel, on the turn engine's layout
   b.store_army(army);
+  b.settle_lists();
   b.store_hdr(hdr, A.fresh ? 0u : ((b.hdr_get(H_STATUS) >> 16) & 0xFFu));
   b.store_planes(rows, A.fd, A.row_dw, true);
 }
@@ -1014,8 +1019,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
     load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
     b.hflags &= ~HF_WIDE;
     army_store_wide<NSLOT>(b.army, rec_army);
+    b.settle_lists();
     b.store_hdr(rec_hdr, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);
-    b.store_planes(rec_rows, A.fd, A.row_dw, true);
+    b.store_planes(rec_rows, A.fd, A.row_dw, true, true);  // a record carries its list planes whatever the flag says
   } else {
     b.load_hdr(rec_hdr);
     const bool bad = b.W < 1 || b.W > A.max_w || b.H < 1 || b.H > A.max_h || b.P < 1 || b.P > A.max_p || b.P > MAXP ||
@@ -1024,7 +1030,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
       if (lane == 0) atomicExch(A.status, GVEC_E_BOARD);
       return;
     }
-    b.hflags &= (HF_DONE | HF_FOG);
+    b.hflags &= (HF_DONE | HF_FOG | HF_LDIFF);  // HF_LDIFF: where load_planes takes the lists from
     army_load_wide<NSLOT>(b.army, rec_army);
     b.load_planes(rec_rows, A.fd);
     b.geometry();  // the constant planes are rebuilt, never taken from the slab
@@ -1047,6 +1053,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void records_kernel(RecordArg
     b.static_flags();
     b.refresh_gt1();
     b.store_army(army_ref<NSLOT>(A.army16, A.army32, env));
+    b.settle_lists();
     b.store_hdr(A.hdr + (size_t)env * HDR_DW, (b.hdr_get(H_STATUS) >> 16) & 0xFFu);
     b.store_planes(A.rows + (size_t)env * A.row_dw, A.fd, A.row_dw, true);
   }

@@ -105,7 +105,7 @@ struct PBoard {
   uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
   uint32_t valid, ncol0, ncolL, ok[4];        // replicated constant planes (see Board)
   uint32_t rowbit[NR];                        // 1 << (the player this lane holds in register k)
-  static constexpr int NSHARED = PL::COUNT - PL::CHG;           // the 13 shared planes, CHG .. OK[3], contiguous in the block
+  static constexpr int NSHARED = PL::SHARED;                    // the 13 shared planes, CHG .. OK[3], contiguous in the block
   static constexpr int NSR = (NSHARED + PPR - 1) / PPR;         // ... loaded PPR at a time, like the packed ones
   uint32_t shp[NSR];                          // in flight between load_planes and spread_shared: row r of shp[k] = shared plane k*PPR + r
   int32_t army[NSLOT];                        // tile domain, as in Board
@@ -265,13 +265,12 @@ struct PBoard {
       // block makes its cache lines a hot spot of the L2 channels they live in)
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        own[k] = lst[k] = vis[k] = 0u;
+        own[k] = vis[k] = 0u;
         if (in && (k * PPR + row() < MAXP)) {
           own[k] = ld_stream(lane_base + (PL::OWN + k * PPR) * fd);
-          lst[k] = ld_stream(lane_base + (PL::LST + k * PPR) * fd);
           vis[k] = ld_stream(lane_base + (PL::VIS + k * PPR) * fd);
         }
-      }
+      }  // the lists: load_lists(), once the header has landed
 #pragma unroll
       for (int k = 0; k < NSR; ++k) {
         shp[k] = 0u;
@@ -282,9 +281,9 @@ struct PBoard {
       for (int k = 0; k < NR; ++k) {
         const uint32_t* gp = (in && (k * PPR + row() < MAXP)) ? lane_base : zeros;  // packed: plane (base + row), dword col
         own[k] = ld_stream(gp + (PL::OWN + k * PPR) * fd);
-        lst[k] = ld_stream(gp + (PL::LST + k * PPR) * fd);
         vis[k] = ld_stream(gp + (PL::VIS + k * PPR) * fd);
       }
+      load_lists(rows_env, fd);  // this order has the header already
       const uint32_t* gs = in ? rows_env + col() : zeros;
       chg = ld_stream(gs + PL::CHG * fd);
       vch = ld_stream(gs + PL::VCH * fd);
@@ -298,6 +297,29 @@ struct PBoard {
 #pragma unroll
       for (int d = 0; d < 4; ++d) ok[d] = ld_stream(gs + (PL::OK + d) * fd);
     }
+  }
+  // OwnedTiles: the board's ownership unless the header says otherwise (HF_LDIFF: a second round trip, for the few
+  // envs an aborted turn has left out of step, H6).  Needs hflags and own[].
+  __device__ __forceinline__ void load_lists(const uint32_t* rows_env, int fd) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) lst[k] = own[k];
+    if (hflags & HF_LDIFF) {
+      const uint32_t* lane_base = rows_env + (row() * fd + col());
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        lst[k] = 0u;
+        if (col() < fd && (k * PPR + row() < MAXP)) lst[k] = lane_base[(PL::LST + k * PPR) * fd];
+      }
+    }
+  }
+  // Sets HF_LDIFF to what the lists are now: call BEFORE store_hdr; the plane stores write the lists accordingly.
+  __device__ __forceinline__ void settle_lists() { hflags = lists_match() ? (hflags & ~HF_LDIFF) : (hflags | HF_LDIFF); }
+  __device__ __forceinline__ void store_lists(uint32_t* rows_env, int fd) const {
+    if (!(hflags & HF_LDIFF)) return;
+    uint32_t* gp = rows_env + row() * fd + col();
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (col() < fd && (k * PPR + row() < MAXP)) gp[(PL::LST + k * PPR) * fd] = lst[k];
   }
   // shared plane j (CHG + j), replicated in every row
   __device__ __forceinline__ uint32_t shared_plane(int j) const { return bperm((((j % PPR) * ROWL) + col()) << 2, shp[j / PPR]); }
@@ -322,10 +344,10 @@ struct PBoard {
     for (int k = 0; k < NR; ++k) {
       if (in && (k * PPR + row() < MAXP)) {
         st_stream<GVEC_NT_PLANE>(gp + (PL::OWN + k * PPR) * fd, own[k]);
-        st_stream<GVEC_NT_PLANE>(gp + (PL::LST + k * PPR) * fd, lst[k]);
         st_stream<GVEC_NT_PLANE>(gp + (PL::VIS + k * PPR) * fd, vis[k]);
       }
     }
+    store_lists(rows_env, fd);
     static_assert(PL::VCH == PL::CHG + 1 && PL::GT1 == PL::CHG + 2, "the three mutable shared planes are stored as rows of one register");
 #pragma unroll
     for (int k = 0; k * PPR < 3; ++k) {
@@ -343,10 +365,10 @@ struct PBoard {
         g[PL::NCOL0 * fd] = ncol0;
         g[PL::NCOLL * fd] = ncolL;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) g[(PL::OK + d) * fd] = ok[d];
+        for (int d = 0; d < 4; ++d) g[(PL::OK + d) * fd] = ok[d];
       }
     }
-    if (with_types && lane < row_dw - (PL::OK + 3) * fd) rows_env[(PL::OK + 3) * fd + lane] = (lane < fd) ? ok[3] : 0u;  // + the block's padding
+    if (with_types && lane < row_dw - PL::COUNT * fd) rows_env[PL::COUNT * fd + lane] = 0u;  // the block's padding
   }
   // narrow (u16 pairs) / wide (int32 escape) army storage: see gvec_device.hpp "army storage"
   __device__ __forceinline__ void load_army(const ArmyCRef& a) {
@@ -989,7 +1011,6 @@ struct PBoard {
     for (int k = 0; k < NR; ++k) {
       if (in && (k * PPR + row() < MAXP)) {
         g[(PL::OWN + k * PPR) * fd] = own[k];
-        g[(PL::LST + k * PPR) * fd] = lst[k];
         g[(PL::VIS + k * PPR) * fd] = vis[k];
       }
     }
@@ -1000,6 +1021,7 @@ struct PBoard {
     }
     wave_lds_fence();
     flush_stage<GVEC_NT_PLANE>(rows_env, PL::MUTABLE * fd);
+    store_lists(rows_env, fd);
   }
   // narrow armies (the caller has checked army_fits_narrow): the block's layout is army_store_narrow's
   __device__ __forceinline__ void store_army_narrow_staged(uint32_t* n) const {
