@@ -488,15 +488,12 @@ struct PBoard {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const uint32_t d = dil3(lst[k]);
+      // affected: some lane of my row holds an owned tile near V - the row's slice of the ballot, looked at from the
+      // lanes (a per-player scalar loop costs five scalar instructions a player; the scalar unit is the busier one)
       const unsigned long long hit = __builtin_amdgcn_ballot_w64((matched ? (d & near3) : (own[k] & near5)) != 0u);
-      uint32_t relight = 0u;  // per-player bit set, wave-uniform
-#pragma unroll
-      for (int r = 0; r < PPR; ++r) {
-        const unsigned long long rowbits = (ROWL == 32) ? 0xFFFFFFFFull : 0xFFFFull;
-        relight |= ((hit >> (r * ROWL)) & rowbits) ? (1u << (k * PPR + r)) : 0u;
-      }
-      relight &= alive;
-      vis[k] = (vis[k] & clr) | (lane_flag(relight, k) ? d : 0u);
+      const uint32_t mine = (uint32_t)(hit >> (row() * ROWL)) & (ROWL == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+      const bool relit = mine != 0u && lane_flag(alive, k);
+      vis[k] = (vis[k] & clr) | (relit ? d : 0u);
     }
   }
 
@@ -606,28 +603,24 @@ struct PBoard {
       hv = (lane >= H_ARMYCNT && lane < H_ARMYCNT + MAXP) ? tot : hv;
       hflags |= HF_SYNC;
     }
-    alive = 0u;
+    // GeneralIdx / Alive (:46,52-54 / :101,122,133-135).  The reference keeps the last general in list order; with two or
+    // more generals that order depends on Go map iteration.  Here: the highest listed general tile - found on lanes:
+    // every lane's candidate, the row's maximum by DPP, one ds_bpermute hands row p's result to header lane H_GIDX + p.
+    {
+      const int hl = lane - H_GIDX;  // the player whose GeneralIdx this header lane holds
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const uint32_t g = lst[k] & gen;
-      const unsigned long long nz = __builtin_amdgcn_ballot_w64(g != 0u);
-#pragma unroll
-      for (int r = 0; r < PPR; ++r) {
-        const int p = k * PPR + r;
-        if (p < MAXP) {
-          // GeneralIdx: the reference keeps the last general in list order (:46,:101,:122); with two or more
-          // generals that order depends on Go map iteration.  Here: the highest listed general tile.
-          const unsigned long long rowbits = (ROWL == 32) ? 0xFFFFFFFFull : 0xFFFFull;
-          const uint32_t dw = (uint32_t)((nz >> (r * ROWL)) & rowbits);
-          int gi = -1;
-          if (dw) {
-            const int i = 31 - __builtin_clz(dw);
-            gi = 32 * i + (31 - __builtin_clz(rdlane(g, r * ROWL + i)));
-          }
-          hdr_set(H_GIDX + p, (uint32_t)gi);
-          alive |= (gi >= 0) ? (1u << p) : 0u;  // :52-54 / :133-135
-        }
+      for (int k = 0; k < NR; ++k) {
+        const uint32_t g = lst[k] & gen;
+        int32_t v = (g != 0u) ? (32 * col() + 31 - __builtin_clz(g)) : -1;
+        v = max(v, (int32_t)__builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false));  // row_shr:1, lanes without a source keep -1
+        v = max(v, (int32_t)__builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false));
+        v = max(v, (int32_t)__builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false));
+        v = max(v, (int32_t)__builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false));
+        if constexpr (ROWL == 32) v = max(v, (int32_t)__builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false));  // row_bcast15 into DPP rows 1, 3
+        const uint32_t got = bperm((((hl & (PPR - 1)) * ROWL) + ROWL - 1) << 2, (uint32_t)v);
+        hv = (hl >= 0 && hl < MAXP && hl / PPR == k) ? got : hv;
       }
+      alive = (uint32_t)(__builtin_amdgcn_ballot_w64(hl >= 0 && hl < MAXP && (int32_t)hv >= 0) >> H_GIDX) & ((1u << MAXP) - 1u);
     }
   }
 
