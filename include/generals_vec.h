@@ -333,7 +333,9 @@ int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n,
 int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n,
                             const void* src_device);
 /* Zero-copy access for device consumers (torch-ROCm): the handle's resident device
- * arrays.  which: 0 header [B][24] u32, 1 bit-planes, 2 armies (narrow form: u16, two 64-tile slots
+ * arrays.  which: 0 header [B][24] u32, 1 bit-planes (the OwnedTiles planes at the end of an env's block are
+ * meaningful only while its header flag bit 7 is set; otherwise the lists are the ownership planes - DESIGN.md
+ * section 3), 2 armies (narrow form: u16, two 64-tile slots
  * interleaved per dword; authoritative for every env whose header flag bit 2 is clear - see
  * DESIGN.md section 3), 6 armies (wide form: int32, authoritative for the flagged envs), 3 legal masks
  * [B][max_players][mask_bytes], 4 actions [B][max_players], 5 err [B].  Consumers that want plain
