@@ -155,6 +155,7 @@ struct StepArgs {
   int32_t turns, invalid_permille;
   uint32_t agent_noop, agent_half;  // gvec_set_agent_mix thresholds (of 65536)
   uint32_t flags, seed_lo, seed_hi, pool_seed_lo, pool_seed_hi;
+  uint32_t seed_base, pool_seed_base;  // env_key_base of the two seeds: filled in by the launchers (with_seed_bases)
 };
 
 // ---- army storage ------------------------------------------------------------------------
@@ -273,7 +274,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---- the build's counter RNG (DESIGN.md "Synthetic inputs"; mirrored in oracle/) --------
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16;
   h *= 0x85EBCA6Bu;
   h ^= h >> 13;
@@ -281,9 +282,11 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ uint32_t env_key(uint32_t lo, uint32_t hi, uint32_t env) {
-  return fmix32(fmix32(lo ^ 0x9E3779B9u) + hi * 0x85EBCA77u + env * 0xC2B2AE3Du + 0x27D4EB2Fu);
-}
+// env_key(lo, hi, env) = env_key_of(env_key_base(lo, hi), env): the base is a function of the launch's seed alone and
+// is hashed once on the host (StepArgs::seed_base), not once per board on the scalar unit
+__host__ __device__ __forceinline__ uint32_t env_key_base(uint32_t lo, uint32_t hi) { return fmix32(lo ^ 0x9E3779B9u) + hi * 0x85EBCA77u + 0x27D4EB2Fu; }
+__host__ __device__ __forceinline__ uint32_t env_key_of(uint32_t base, uint32_t env) { return fmix32(base + env * 0xC2B2AE3Du); }
+__host__ __device__ __forceinline__ uint32_t env_key(uint32_t lo, uint32_t hi, uint32_t env) { return env_key_of(env_key_base(lo, hi), env); }
 
 // kColumnPattern[W] = sum of 1 << k for k = 0, W, 2W, ... < 32: where column 0 falls in a 32-tile
 // window that starts in column 0

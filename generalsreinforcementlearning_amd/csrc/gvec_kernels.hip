@@ -139,7 +139,7 @@ template <int MAXP, int NSLOT, typename BT>
 __device__ __forceinline__ void redeal(BT& b, const StepArgs& A, int env, int fd, int row_dw) {
   const uint32_t episode = b.hdr_get(H_EPISODE) + 1u;
   const uint32_t cs = b.hdr_get(H_CNT_STEPS), ca = b.hdr_get(H_CNT_ABORT), cd = b.hdr_get(H_CNT_DONE);
-  const uint32_t hk = fmix32(env_key(A.pool_seed_lo, A.pool_seed_hi, (uint32_t)env) ^ (episode * 0x9E3779B1u));
+  const uint32_t hk = fmix32(env_key_of(A.pool_seed_base, (uint32_t)env) ^ (episode * 0x9E3779B1u));
   const int j = (int)__umulhi(hk, (uint32_t)A.pool_size);
   load_turn(b, A.pool_hdr + (size_t)j * HDR_DW, A.pool_rows + (size_t)j * row_dw, army_cref<NSLOT>(A.pool_army16, A.pool_army32, j), fd, A.zeros);
   b.hdr_set(H_EPISODE, episode);
@@ -211,13 +211,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
       // the agent's input: the legal-move planes of the resident state, rebuilt from the stored gt1 plane
       // (7 vector instructions; re-reading the 832-byte masks the previous launch wrote would cost more)
       b.template legal_planes<false>(m);
-      uint32_t mine = (GVEC_PROFILE_SKIP & 1) ? 0u : agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+      uint32_t mine = (GVEC_PROFILE_SKIP & 1) ? 0u : agent_sample<MAXP, NSLOT>(b, m, env_key_of(A.seed_base, (uint32_t)env), A);
       if (GVEC_PROFILE_DUP & 64) { b.opaque(); b.template legal_planes<false>(m); }
       if (GVEC_PROFILE_DUP & 1) {
         b.opaque();
 #pragma unroll
         for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(m[0][d]));
-        const uint32_t again = agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A);
+        const uint32_t again = agent_sample<MAXP, NSLOT>(b, m, env_key_of(A.seed_base, (uint32_t)env), A);
         asm volatile("" : : "v"(again));
       }
       av = agent_actvec<MAXP, NSLOT>(b, mine, A.invalid_permille > 0);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, rollout_waves(MAXP, NSLOT)) v
   load_turn(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_env, A.fd, A.zeros);
   uint32_t m[B::NR][4];
   uint32_t err = 0u, n_steps = 0u, n_abort = 0u, n_done = 0u;
-  const uint32_t ek = env_key(A.seed_lo, A.seed_hi, (uint32_t)env);
+  const uint32_t ek = env_key_of(A.seed_base, (uint32_t)env);
   const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
   int k = 0;
   // The hot inner loop plays turns while the game is live; the rare events (game over: re-deal from
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void query_kernel(StepArgs A)
   else b.template legal_planes<false>(m);
   if constexpr (MODE == 1) {
     uint32_t alo = 0u, ahi = 0u;
-    if (!(b.hflags & HF_DONE)) agent_words<MAXP, NSLOT>(b, agent_sample<MAXP, NSLOT>(b, m, env_key(A.seed_lo, A.seed_hi, (uint32_t)env), A), alo, ahi);
+    if (!(b.hflags & HF_DONE)) agent_words<MAXP, NSLOT>(b, agent_sample<MAXP, NSLOT>(b, m, env_key_of(A.seed_base, (uint32_t)env), A), alo, ahi);
     if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(alo, ahi);
   } else {
     b.store_masks(m, A.legal + (size_t)env * A.pstride * A.mask_dw, A.fd, A.pstride);
@@ -1279,7 +1279,15 @@ static hipError_t dispatch(const Variant& v, F&& f) {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
 
-hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
+static inline StepArgs with_seed_bases(const StepArgs& in) {
+  StepArgs a = in;
+  a.seed_base = env_key_base(a.seed_lo, a.seed_hi);
+  a.pool_seed_base = env_key_base(a.pool_seed_lo, a.pool_seed_hi);
+  return a;
+}
+
+hipError_t launch_step(const Variant& v, const StepArgs& in, hipStream_t s) {
+  const StepArgs a = with_seed_bases(in);
   return dispatch(v, [&](auto P_, auto S_) {
     constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
     // the resident format keeps planes of 2*S-1 or 2*S dwords (gvec_api.hip: plane_dwords)
@@ -1293,14 +1301,16 @@ hipError_t launch_step(const Variant& v, const StepArgs& a, hipStream_t s) {
     return hipGetLastError();
   });
 }
-hipError_t launch_rollout(const Variant& v, const StepArgs& a, hipStream_t s) {
+hipError_t launch_rollout(const Variant& v, const StepArgs& in, hipStream_t s) {
+  const StepArgs a = with_seed_bases(in);
   return dispatch(v, [&](auto P_, auto S_) {
     constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
     hipLaunchKernelGGL((rollout_kernel<P, S>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }
-hipError_t launch_agent(const Variant& v, const StepArgs& a, hipStream_t s) {
+hipError_t launch_agent(const Variant& v, const StepArgs& in, hipStream_t s) {
+  const StepArgs a = with_seed_bases(in);
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((query_kernel<decltype(P_)::value, decltype(S_)::value, 1>), wave_grid(a.num_envs),
                        dim3(64 * WAVES_PER_BLOCK), 0, s, a);
