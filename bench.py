@@ -180,11 +180,13 @@ def rehearse_cpu(args):
         eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
     dist.barrier()
     t0 = time.perf_counter()
+    K = max(1, args.gather_every)
     for k in range(args.steps):
-        if rg is not None:
+        gathering = rg is not None and k % K == K - 1
+        if gathering:
             eng.experience_begin_range(0, ge)
         eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
-        if rg is not None:
+        if gathering:
             eng.experience_records(rg.send.data_ptr(), None, 0, ge, rank * B)
             rg.send.fill_((rank * 31 + k) % 251)
             out = rg.gather()
@@ -220,6 +222,10 @@ def main():
     ap.add_argument("--pool", type=int, default=4096)
     ap.add_argument("--gather-envs", type=int, default=4096,
                     help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N>1 only: the record gather runs on every K-th step (BASELINE configs[3]: 'RCCL gather each K turns')")
+    ap.add_argument("--gather-mode", type=int, default=0,
+                    help="diagnostics: 1 = record kernels only (no collective), 2 = collective on the compute stream (no side stream)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]: env i gets a 10x10 / 15x15 / 20x20 board with 2 + i%%3 players in one padded batch "
                          "(a parity-test configuration, not the bench line)")
@@ -283,22 +289,31 @@ def main():
         rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)]
         slab_free = [None, None]
         side = torch.cuda.Stream()
-        eng.record_agent_actions(True)                            # the record needs the moves the device agent played
+
+    K = max(1, args.gather_every)
 
     def one_step(k):
-        if rgs is not None:
+        gathering = rgs is not None and k % K == K - 1
+        if gathering:
             ge = min(args.gather_envs, B)
-            lo = (k * ge) % max(1, B - ge + 1)
+            lo = ((k // K) * ge) % max(1, B - ge + 1)
             eng.experience_begin_range(lo, ge)                    # captureStateForExperience for the sampled slice
+            eng.record_agent_actions(True)                        # the record needs the moves the device agent plays in this step
         eng.rollout(1, seed, 0, fused=False, want_stats=False)
-        if rgs is not None:
-            i = k & 1
+        if gathering:
+            eng.record_agent_actions(False)
+            i = (k // K) & 1
             if slab_free[i] is not None:
-                stream.wait_event(slab_free[i])                   # slab i was last read by the gather of step k-2
+                stream.wait_event(slab_free[i])                   # slab i was last read by the gather before the previous one
             eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, rank * B)   # compute stream, after this step's kernel
+            if args.gather_mode == 1:
+                return
+            if args.gather_mode == 2:
+                rgs[i].gather()
+                return
             side.wait_stream(stream)
             with torch.cuda.stream(side):
-                rgs[i].gather()                                    # RCCL gather over xGMI, overlapped with the next step
+                rgs[i].gather()                                    # RCCL gather over xGMI, overlapped with the next steps
                 slab_free[i] = side.record_event()
 
     def sync_all():
@@ -352,9 +367,11 @@ def main():
         from generalsreinforcementlearning_amd.experience import decode_records
         torch.cuda.synchronize()
         lay = eng.experience_record_layout()
-        last = rgs[(args.warmup + args.steps - 1) & 1].recv
+        n_g = (args.warmup + args.steps) // K                      # gathers so far; the last one filled slab (n_g - 1) & 1
+        last = rgs[(n_g - 1) & 1].recv if n_g > 0 else []
         decs = [decode_records(t.cpu().numpy(), lay, drop_invalid=True) for t in last]
-        gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_step": min(args.gather_envs, B),
+        gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_gather": min(args.gather_envs, B),
+                    "gather_every_steps": K,
                     "experiences_decoded_last_step": int(sum(len(d["env"]) for d in decs)),
                     "ranks_seen": sorted({int(e) // B for d in decs for e in d["env"]})}
     if rank == 0:
@@ -388,7 +405,8 @@ def main():
             "config": {"workload": f"{mode_txt} x {W}x{H} {P}P fog-{'on' if args.fog else 'off'} + legal mask, on-device random "
                                    f"agent, auto-reset pool {args.pool}, 1 turn per launch",
                        "envs_per_gpu": B, "total_envs": total_envs, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
-                       "gather_envs_per_step": (args.gather_envs if rgs is not None else 0)},
+                       "gather_envs_per_step": (args.gather_envs if rgs is not None else 0),
+                       "gather_every_steps": (K if rgs is not None else 0)},
             # achieved / frac: ALGORITHMIC bytes over the kernel's measured time - the contract's figure.
             # traffic_*: the bytes the kernel really moves (PMC), when a record for this build exists.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
