@@ -414,7 +414,10 @@ def main():
                          "traffic_gbs": (traffic / (kernel_ms / 1e3) / 1e9 if traffic else None),
                          "traffic_frac": (traffic / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS if traffic else None),
                          "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
-                         "units_per_launch": B, "kernel_ms": kernel_ms},
+                         "units_per_launch": B, "kernel_ms": kernel_ms,
+                         "note": "achieved / frac price SURVEY 8(d)'s ALGORITHMIC bytes (8 B per tile each way, int32 armies): the kernel "
+                                 "stores armies as u16 and lists on demand and moves about 64 % of them, so frac can pass 1; "
+                                 "traffic_frac is the HBM's own utilisation (PMC bytes of this build / kernel time / peak)"},
         }
         if gathered:
             out["experience_gather"] = gathered
