@@ -75,6 +75,7 @@ __device__ __forceinline__ void st_through(uint32_t* p, uint32_t v) { asm volati
 __device__ __forceinline__ void st_through(uint16_t* p, uint16_t v) {
   asm volatile("global_store_short %0, %1, off sc1 nt" : : "v"(p), "v"((uint32_t)v) : "memory");
 }
+__device__ __forceinline__ void st_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_through(u32x4* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
 }

@@ -617,15 +617,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
       const float arm = (b.army[s] > 0) ? norm : 0.0f;
       if (t < b.N) {
         const size_t n = (size_t)b.N;
-        out[0 * n + t] = (open && mine) ? arm : 0.0f;
-        out[1 * n + t] = (open && !mine && owned) ? arm : 0.0f;
-        out[2 * n + t] = (open && mine) ? 1.0f : 0.0f;
-        out[3 * n + t] = (open && !mine && owned) ? 1.0f : 0.0f;
-        out[4 * n + t] = (open && !owned) ? 1.0f : 0.0f;
-        out[5 * n + t] = (open && spec) ? 1.0f : 0.0f;
-        out[6 * n + t] = (visible && mount) ? 1.0f : 0.0f;
-        out[7 * n + t] = visible ? 1.0f : 0.0f;
-        out[8 * n + t] = visible ? 0.0f : 1.0f;
+        // 14.4 KB per (env, player) that the kernel never reads back: streamed past the L2 like the turn's own stores
+        st_stream<GVEC_NT_MASK>(out + 0 * n + t, (open && mine) ? arm : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 1 * n + t, (open && !mine && owned) ? arm : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 2 * n + t, (open && mine) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 3 * n + t, (open && !mine && owned) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 4 * n + t, (open && !owned) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 5 * n + t, (open && spec) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 6 * n + t, (visible && mount) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 7 * n + t, visible ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(out + 8 * n + t, visible ? 0.0f : 1.0f);
       }
     }
     // a smaller board in a padded batch: clear the rest of the slot
