@@ -108,7 +108,7 @@ template <int POL> __device__ __forceinline__ void stx4(u32x4* p, u32x4 v) {
   else if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
 }
-template <bool LOADS, int POL = 0>
+template <bool LOADS, int POL = 0, bool OUT = false>
 __global__ __launch_bounds__(256, 8) void wide(Args a) {
   const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int lane = threadIdx.x & 63;
@@ -137,19 +137,24 @@ __global__ __launch_bounds__(256, 8) void wide(Args a) {
   }
   h.x += 1u; r0.y ^= r1.x; q.z += 1u;
   if constexpr (LOADS) { if (lane < 6) __builtin_nontemporal_store(h, hdr + lane); }
-  else if (lane < 24) __builtin_nontemporal_store(h.x, a.hdr + (size_t)env * 24 + lane);
+  else if (lane < 24) __builtin_nontemporal_store(h.x, (OUT ? a.hdr2 : a.hdr) + (size_t)env * 24 + lane);
+  if constexpr (OUT) {  // ping-pong: the state goes to the second buffer set
+    hdr = reinterpret_cast<u32x4*>(a.hdr2 + (size_t)env * 24);
+    rows = reinterpret_cast<u32x4*>(a.rows2 + (size_t)env * 328);
+    army = reinterpret_cast<u32x4*>(a.army2 + (size_t)env * 224);
+  }
   if (lane < 48) stx4<POL>(rows + lane, r0);
-  if (lane < 3) __builtin_nontemporal_store(r1.x, a.rows + (size_t)env * 328 + 192 + lane);
+  if (lane < 3) __builtin_nontemporal_store(r1.x, (OUT ? a.rows2 : a.rows) + (size_t)env * 328 + 192 + lane);
   if (lane < 56) stx4<POL>(army + lane, q);
   if (lane < 52) stx4<POL>(mask + lane, r0 + q);
 }
-template <bool LOADS, int POL = 0>
+template <bool LOADS, int POL = 0, bool OUT = false>
 void run_wide(const Args& a, const char* what) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     (void)hipEventRecord(e0);
-    for (int it = 0; it < 40; ++it) hipLaunchKernelGGL((wide<LOADS, POL>), dim3(a.n / 4), dim3(256), 0, 0, a);
+    for (int it = 0; it < 40; ++it) hipLaunchKernelGGL((wide<LOADS, POL, OUT>), dim3(a.n / 4), dim3(256), 0, 0, a);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep && ms < best) best = ms;
@@ -194,6 +199,8 @@ int main() {
   run_wide<false, 4>(a, "wide stores, nt sc1");
   run_wide<false, 5>(a, "wide stores, nt sc0 sc1");
   run_wide<false, 6>(a, "wide stores, sc0");
+  run_wide<false, 4, true>(a, "wide stores, nt sc1, OUT OF PLACE (ping-pong)");
+  run_wide<false, 4>(a, "wide stores, nt sc1 (again)");
   run<2 | 128, 8>(a, "  + planes as 3 packed + 13 replicated loads, zero block");
   run<2 | 128 | 256, 8>(a, "  + header fields through the scalar cache");
   run<2 | 128 | 256 | 512, 8>(a, "  + err store");
