@@ -99,7 +99,10 @@ struct PBoard {
   static constexpr bool FULL_ROWS = (2 * NSLOT >= ROWL);  // a plane can fill its row: shifts must not cross rows
   // LDS scratch of the vector action phase: three ROWL-dword tile bitmaps (candidate tiles, changed, captured), one
   // 64-dword image per packed ownership register (the bits captures set) and 8 dwords of army lost per defending player
-  static constexpr int ACT_SCRATCH_DW = 3 * ROWL + 64 * NR + 8;
+  // ... and 64 dwords where the lanes that have nothing to write put it (an address select instead of an exec-mask region:
+  // the scalar unit, not the vector unit, is the busy one), the whole rounded to 64 so that clearing it needs no mask
+  static constexpr int ACT_DUMMY = 3 * ROWL + 64 * NR + 8;
+  static constexpr int ACT_SCRATCH_DW = (ACT_DUMMY + 64 + 63) / 64 * 64;
 
   uint32_t own[NR], lst[NR], vis[NR];         // packed: row r of register k = player k*PPR + r
   uint32_t chg, vch, gt1, gen, city, mtn;     // replicated in every row
@@ -402,6 +405,7 @@ struct PBoard {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) army[s] = larmy[64 * s + lane_id()];
   }
+  static __device__ __forceinline__ void larmy_store(int32_t* p, int32_t v) { *p = v; }
   __device__ __forceinline__ int army_get(int t) const { return uni(larmy[t]); }
   __device__ __forceinline__ void army_set(int t, int val) {
     if (lane_id() == 0) larmy[t] = val;
@@ -762,9 +766,9 @@ struct PBoard {
     uint32_t* s_cap = lscr + 2 * ROWL;
     uint32_t* s_own = lscr + 3 * ROWL;
     uint32_t* s_loss = lscr + 3 * ROWL + 64 * NR;
+    uint32_t* s_dummy = lscr + ACT_DUMMY + lane;  // per lane: where an inactive lane's LDS writes land
 #pragma unroll
-    for (int i = 0; i < (ACT_SCRATCH_DW + 63) / 64; ++i)
-      if (64 * i + lane < ACT_SCRATCH_DW) lscr[64 * i + lane] = 0u;
+    for (int i = 0; i < ACT_SCRATCH_DW / 64; ++i) lscr[64 * i + lane] = 0u;
     const uint32_t m = av.meta;
     const bool active = lane < P && (m & 16u) != 0u && ((alive >> lane) & 1u) != 0u;  // action_processor.go:56-60 (H2)
     const uint32_t scode = m & 15u;
@@ -773,13 +777,11 @@ struct PBoard {
     const uint32_t fbit = 1u << (ft & 31), tbit = 1u << (tt & 31);
     const int fcol = ft >> 5, tcol = tt >> 5;
     wave_lds_fence();
-    if (cand) {
-      atomicOr(&s_cand[fcol], fbit);
-      atomicOr(&s_cand[tcol], tbit);
-    }
+    atomicOr(cand ? &s_cand[fcol] : s_dummy, fbit);
+    atomicOr(cand ? &s_cand[tcol] : s_dummy, tbit);
     wave_lds_fence();
-    const uint32_t cb = (lane < ROWL) ? s_cand[lane & (ROWL - 1)] : 0u;
-    const int distinct = (int)rdlane(row_scan_add<ROWL>((uint32_t)__builtin_popcount(cb)), ROWL - 1);
+    // every row sums the same ROWL dwords: no lane needs masking, row 0's last lane is read
+    const int distinct = (int)rdlane(row_scan_add<ROWL>((uint32_t)__builtin_popcount(s_cand[lane & (ROWL - 1)])), ROWL - 1);
     const int ncand = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand));
     if (distinct != 2 * ncand) return false;  // two moves meet on a tile: order matters
     // pre-turn facts of my move
@@ -801,12 +803,13 @@ struct PBoard {
     const bool mine_tt = ((owner_bits >> lane) & 1u) != 0u;  // lane < MAXP wherever it matters (cand)
     const bool mtn_tt = ((bperm(tcol << 2, mtn) >> (tt & 31)) & 1u) != 0u;
     const bool gen_tt = ((bperm(tcol << 2, gen) >> (tt & 31)) & 1u) != 0u;
-    // MoveAction.Validate, the state-dependent half, in the reference's order (action.go:82-98)
-    uint32_t code = scode;
-    code = (cand && mtn_tt) ? GVEC_ERR_TARGET_IS_MOUNTAIN : code;
-    code = (cand && fa <= 1) ? GVEC_ERR_INSUFFICIENT_ARMY : code;
-    code = (cand && !own_ft) ? GVEC_ERR_NOT_OWNED : code;
-    const bool ok = cand && code == 0u;
+    // MoveAction.Validate, the state-dependent half, in the reference's order (action.go:82-98): the last assignment
+    // that applies is the first check that fails
+    uint32_t dyn = mtn_tt ? GVEC_ERR_TARGET_IS_MOUNTAIN : 0u;
+    dyn = (fa <= 1) ? GVEC_ERR_INSUFFICIENT_ARMY : dyn;
+    dyn = own_ft ? dyn : GVEC_ERR_NOT_OWNED;
+    const uint32_t code = cand ? dyn : scode;
+    const bool ok = cand && dyn == 0u;
     {  // the FIRST error in PlayerID order (action_processor.go:66-77)
       const unsigned long long em = __builtin_amdgcn_ballot_w64(active && code != 0u);
       if (em && !first_err) first_err = rdlane(code, (int)__builtin_ctzll(em));
@@ -814,23 +817,22 @@ struct PBoard {
     // core.ApplyMoveAction (movement.go:40-86)
     int32_t n = (m & 32u) ? (fa >> 1) : (fa - 1);  // fa >= 2 where it matters
     n = n < 1 ? 1 : n;
-    const bool capture = ok && !mine_tt && n > ta;  // ties favour the defender
-    const int32_t new_ta = mine_tt ? ta + n : (capture ? n - ta : ta - n);
-    if (ok) {
-      larmy[ft] = fa - n;
-      larmy[tt] = new_ta;
-      atomicOr(&s_chg[fcol], fbit);  // :57-60
-      atomicOr(&s_chg[tcol], tbit);
-    }
-    if (capture) {
-      atomicOr(&s_cap[tcol], tbit);                            // action_processor.go:84-86
-      atomicOr(&s_own[64 * (lane / PPR) + myrow + tcol], tbit);  // :69-82 the tile is mine now
-    }
+    const bool take = !mine_tt && n > ta;  // ties favour the defender
+    const bool capture = ok && take;
+    const int32_t fight = take ? n - ta : ta - n;
+    const int32_t new_ta = mine_tt ? ta + n : fight;
+    larmy_store(ok ? &larmy[ft] : reinterpret_cast<int32_t*>(s_dummy), fa - n);
+    larmy_store(ok ? &larmy[tt] : reinterpret_cast<int32_t*>(s_dummy), new_ta);
+    atomicOr(ok ? &s_chg[fcol] : s_dummy, fbit);  // :57-60
+    atomicOr(ok ? &s_chg[tcol] : s_dummy, tbit);
+    atomicOr(capture ? &s_cap[tcol] : s_dummy, tbit);                              // action_processor.go:84-86
+    atomicOr(capture ? &s_own[64 * (lane / PPR) + myrow + tcol] : s_dummy, tbit);  // :69-82 the tile is mine now
     // What the move does to the armies on LISTED tiles when lists equal ownership (update_stats' delta path): on my own
     // tile nothing moves out of my hands; anywhere else the fight burns `loss` on both sides - mine (-n at the source,
     // + n - ta at a captured target) and the previous owner's (the tile's ta with the tile, or n off its army).
-    const int32_t loss = (ok && !mine_tt) ? (capture ? ta : n) : 0;
-    if (loss != 0 && owner_bits != 0u) atomicAdd(&s_loss[__builtin_ctz(owner_bits)], (uint32_t)loss);
+    const int32_t burnt = take ? ta : n;
+    const int32_t loss = (ok && !mine_tt) ? burnt : 0;
+    atomicAdd((loss != 0 && owner_bits != 0u) ? &s_loss[__builtin_ctz(owner_bits | 0x80000000u) & 7] : s_dummy, (uint32_t)loss);
     wave_lds_fence();
     move_delta = -(loss + (int32_t)s_loss[lane & 7]);
     const uint32_t capbits = s_cap[col()];
