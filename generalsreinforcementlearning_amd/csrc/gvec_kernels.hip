@@ -666,6 +666,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
   const uint32_t m0 = src & b.ok[0], m1 = src & b.ok[1], m2 = src & b.ok[2], m3 = src & b.ok[3], many = m0 | m1 | m2 | m3;
   float* obs = A.obs + (size_t)env * 9 * (size_t)A.stride;
   uint8_t* mask = A.mask + (size_t)env * 5 * (size_t)A.stride;
+  // the mask is five bytes per tile: laid out in LDS first and stored as whole 16-byte (or 4-byte) pieces of consecutive
+  // lanes - five byte stores per lane and slot, each lane 5 bytes from its neighbour, held this kernel at 1.4 TB/s
+  __shared__ uint32_t mask_stage[WAVES_PER_BLOCK][(NSLOT * 64 * 5 + 15) / 16 * 4];
+  uint8_t* ms = reinterpret_cast<uint8_t*>(mask_stage[wave]);
   // channel 7: min(turn_count / max_turns, 1.0) in float64, stored as float32 (:338-339)
   double tcn = (double)A.turn_count[env] / (double)A.max_turns;
   tcn = tcn < 1.0 ? tcn : 1.0;
@@ -682,21 +686,36 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
     if (t < A.stride) {
       const bool in = t < b.N;
       const size_t n = (size_t)A.stride;
-      obs[0 * n + t] = (in && vis) ? 1.0f : 0.0f;                                // :312-314
-      obs[1 * n + t] = (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f);   // :316-322 (owner -1 unless visible)
-      obs[2 * n + t] = in ? la : 0.0f;
-      obs[3 * n + t] = (in && !g && !c && !mt) ? 1.0f : 0.0f;                    // :328-336 one-hot type
-      obs[4 * n + t] = (in && mt) ? 1.0f : 0.0f;
-      obs[5 * n + t] = (in && c) ? 1.0f : 0.0f;
-      obs[6 * n + t] = (in && g) ? 1.0f : 0.0f;
-      obs[7 * n + t] = tc;                                                       // the whole plane, like obs[7, :, :] = ...
-      obs[8 * n + t] = 0.0f;                                                     // left zero by the reference (:341-343)
-      uint8_t* mk = mask + (size_t)t * 5;
+      st_stream<GVEC_NT_MASK>(obs + 0 * n + t, (in && vis) ? 1.0f : 0.0f);                                // :312-314
+      st_stream<GVEC_NT_MASK>(obs + 1 * n + t, (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f));   // :316-322 (owner -1 unless visible)
+      st_stream<GVEC_NT_MASK>(obs + 2 * n + t, in ? la : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 3 * n + t, (in && !g && !c && !mt) ? 1.0f : 0.0f);                    // :328-336 one-hot type
+      st_stream<GVEC_NT_MASK>(obs + 4 * n + t, (in && mt) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 5 * n + t, (in && c) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 6 * n + t, (in && g) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 7 * n + t, tc);                                                       // the whole plane, like obs[7, :, :] = ...
+      st_stream<GVEC_NT_MASK>(obs + 8 * n + t, 0.0f);                                                     // left zero by the reference (:341-343)
+      uint8_t* mk = ms + t * 5;
       mk[0] = (uint8_t)k0;
       mk[1] = (uint8_t)k1;
       mk[2] = (uint8_t)k2;
       mk[3] = (uint8_t)k3;
       mk[4] = (uint8_t)k4;
+    }
+  }
+  wave_lds_fence();
+  {
+    const int nbytes = 5 * A.stride;
+    if ((nbytes & 15) == 0) {  // the env's mask starts on a 16-byte boundary as well
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(ms);
+      u32x4* g4 = reinterpret_cast<u32x4*>(mask);
+      for (int i = lane; i < (nbytes >> 4); i += 64) st_stream<GVEC_NT_MASK>(g4 + i, s4[i]);
+    } else if ((nbytes & 3) == 0) {
+      const uint32_t* s1 = reinterpret_cast<const uint32_t*>(ms);
+      uint32_t* g1 = reinterpret_cast<uint32_t*>(mask);
+      for (int i = lane; i < (nbytes >> 2); i += 64) st_stream<GVEC_NT_MASK>(g1 + i, s1[i]);
+    } else {
+      for (int i = lane; i < nbytes; i += 64) mask[i] = ms[i];
     }
   }
   // _calculate_reward (:499-561) against the stats this kernel stored at its previous call, then store the new ones
