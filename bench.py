@@ -257,7 +257,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        if os.environ.get("GVEC_BENCH_DIST_INIT") == "gloo":
+            # diagnostics (with --gather-envs 0): an RCCL communicator, however and whenever it is created, slows the step
+            # kernel by 5-7 % on this stack (0.215 -> 0.226-0.234 ms at world size 1, kernel time by HIP events); gloo does not
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
