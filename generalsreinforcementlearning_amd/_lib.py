@@ -64,6 +64,7 @@ SYMBOLS = {
     "gvec_experience_records": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gvec_record_agent_actions": (_i32, [_vp, _i32]),
     "gvec_gym_observe": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gvec_gym_finish_step": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvec_gym_actions": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvec_observe": (_i32, [_vp, _i32, _vp, _i32]),
     "gvec_serializer_mask": (_i32, [_vp, _vp, _i32]),

@@ -831,8 +831,27 @@ int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
   return GVEC_OK;
 }
 
+static int32_t gym_observe_impl(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask,
+                                double* reward, uint8_t* done, int8_t* winner, const uint8_t* resetting, const uint8_t* played, int64_t* turn_io,
+                                int64_t* turn_out, uint8_t* terminated, uint8_t* truncated, uint8_t* needs_reset);
+
 int32_t gvec_gym_observe(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask,
                          double* reward, uint8_t* done, int8_t* winner) {
+  return gym_observe_impl(h, player, turn_count, max_turns, obs, mask, reward, done, winner, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr);
+}
+
+int32_t gvec_gym_finish_step(gvec_handle* h, int32_t player, int64_t* turn_count, int32_t max_turns, const uint8_t* resetting,
+                             const uint8_t* played, float* obs, uint8_t* mask, double* reward, uint8_t* terminated, uint8_t* truncated,
+                             int8_t* winner, uint8_t* needs_reset, int64_t* turn_out) {
+  if (!resetting || !played) return GVEC_E_INVALID;
+  return gym_observe_impl(h, player, turn_count, max_turns, obs, mask, reward, nullptr, winner, resetting, played, turn_count, turn_out, terminated,
+                          truncated, needs_reset);
+}
+
+static int32_t gym_observe_impl(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask,
+                                double* reward, uint8_t* done, int8_t* winner, const uint8_t* resetting, const uint8_t* played, int64_t* turn_io,
+                                int64_t* turn_out, uint8_t* terminated, uint8_t* truncated, uint8_t* needs_reset) {
   if (!h || !turn_count || !obs || !mask || player < 0 || player >= h->maxp || max_turns < 1) return GVEC_E_INVALID;
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->d_gym_prev) {
@@ -852,6 +871,13 @@ int32_t gvec_gym_observe(gvec_handle* h, int32_t player, const int64_t* turn_cou
   a.done = done;
   a.winner = winner;
   a.prev_stats = h->d_gym_prev;
+  a.resetting = resetting;
+  a.played = played;
+  a.turn_io = turn_io;
+  a.turn_out = turn_out;
+  a.terminated = terminated;
+  a.truncated = truncated;
+  a.needs_reset = needs_reset;
   a.num_envs = h->cfg.num_envs;
   a.fd = h->fd;
   a.row_dw = h->row_dw;

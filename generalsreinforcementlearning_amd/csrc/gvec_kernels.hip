@@ -670,8 +670,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
   // lanes - five byte stores per lane and slot, each lane 5 bytes from its neighbour, held this kernel at 1.4 TB/s
   __shared__ uint32_t mask_stage[WAVES_PER_BLOCK][(NSLOT * 64 * 5 + 15) / 16 * 4];
   uint8_t* ms = reinterpret_cast<uint8_t*>(mask_stage[wave]);
+  // GeneralsEnv.step's bookkeeping around the observation (generals_env.py:226-259), when asked for: a re-dealt env
+  // restarts its turn count, a refused action leaves it alone
+  const bool flow = A.played != nullptr;
+  const bool rs = flow && A.resetting[env] != 0, pl_ok = !flow || A.played[env] != 0;
+  const int64_t turns = flow ? (rs ? 0 : A.turn_count[env] + (pl_ok ? 1 : 0)) : A.turn_count[env];
   // channel 7: min(turn_count / max_turns, 1.0) in float64, stored as float32 (:338-339)
-  double tcn = (double)A.turn_count[env] / (double)A.max_turns;
+  double tcn = (double)turns / (double)A.max_turns;
   tcn = tcn < 1.0 ? tcn : 1.0;
   const float tc = (float)tcn;
 #pragma unroll
@@ -737,9 +742,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
     for (int q = 0; q < b.P; ++q)                                                 // :548-555
       if (q != pl && prev[2 * MAXP + q] != 0 && !((b.alive >> q) & 1u)) r += 50.0;
     if (over) r = (winner == pl) ? 100.0 : -100.0;                                // :520-524
-    if (A.reward) A.reward[env] = r;
+    if (flow) {
+      // :226-241 a refused action costs -0.1 and changes nothing; :243-259 terminated = game over, truncated = turn limit
+      const bool term = over && pl_ok && !rs, trunc = turns >= (int64_t)A.max_turns && pl_ok && !rs;
+      if (A.reward) A.reward[env] = rs ? 0.0 : (pl_ok ? r : -0.1);
+      if (A.winner) A.winner[env] = (int8_t)(term ? winner : -1);
+      A.turn_io[env] = turns;
+      if (A.turn_out) A.turn_out[env] = turns;
+      if (A.terminated) A.terminated[env] = (uint8_t)(term ? 1 : 0);
+      if (A.truncated) A.truncated[env] = (uint8_t)(trunc ? 1 : 0);
+      if (A.needs_reset) A.needs_reset[env] = (uint8_t)((term || trunc) ? 1 : 0);
+    } else {
+      if (A.reward) A.reward[env] = r;
+      if (A.winner) A.winner[env] = (int8_t)winner;
+    }
     if (A.done) A.done[env] = (uint8_t)(over ? 1 : 0);
-    if (A.winner) A.winner[env] = (int8_t)winner;
   }
   // lanes H_ARMYCNT + p of the header register hold ArmyCount[p]: fetched by every lane (a cross-lane read must
   // not sit under a divergent branch: masked-off source lanes read as 0)

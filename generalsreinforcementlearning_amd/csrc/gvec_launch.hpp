@@ -143,6 +143,14 @@ struct GymArgs {
   uint8_t* done;              // [B] or null
   int8_t* winner;             // [B] or null
   int32_t* prev_stats;        // [B][3*MAXP]: tile_count, army_count, alive as of the previous call (read, then rewritten)
+  // gvec_gym_finish_step only (played == null: plain gvec_gym_observe): GeneralsEnv.step's bookkeeping, per env
+  const uint8_t* resetting;   // [B] in: this step re-dealt the env
+  const uint8_t* played;      // [B] in: the action was submitted (gvec_gym_actions)
+  int64_t* turn_io;           // [B] in / out: turn_count (the same array as turn_count)
+  int64_t* turn_out;          // [B] out: a copy for the caller's info dict
+  uint8_t* terminated;        // [B] out 0/1
+  uint8_t* truncated;         // [B] out 0/1
+  uint8_t* needs_reset;       // [B] out 0/1: terminated | truncated
   int32_t num_envs, fd, row_dw, stride, player, max_turns;
 };
 struct GymActArgs {

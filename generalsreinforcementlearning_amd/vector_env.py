@@ -138,8 +138,9 @@ class GeneralsVecEnv:
                  seed=0, device=0, board_pool=1024, device_outputs=False, numpy_reference=False):
         """Three modes, identical outputs (tests/test_vector_env.py):
         device_outputs=True  observation / mask / reward / flags are torch tensors on the GPU, produced by the gym kernels
-                             (gvec_gym_observe / gvec_gym_actions); `step` takes a CUDA int64 tensor of actions: no board
-                             state crosses PCIe.
+                             (gvec_gym_actions / gvec_gym_finish_step); `step` takes a CUDA int64 tensor of actions: no
+                             board state crosses PCIe, and a step is four kernel launches with no tensor glue between
+                             them.  Every tensor a step returns lives in a buffer that the step AFTER NEXT reuses.
         default              numpy arrays in, numpy arrays out - the same kernels, their outputs copied to pinned host
                              buffers (one D2H of the observation per step instead of a state read-back + numpy rebuild).
         numpy_reference=True numpy arrays built on the host from a state read-back with the pure functions above: the
@@ -185,9 +186,14 @@ class GeneralsVecEnv:
             self._d_mask = [z((num_envs, n * 5), torch.uint8) for _ in range(2)]
             self._d_reward, self._d_done, self._d_winner = z(num_envs, torch.float64), z(num_envs, torch.uint8), z(num_envs, torch.int8)
             self._d_turn = z(num_envs, torch.int64)
-            self._d_needs_reset = z(num_envs, torch.uint8)
             self._d_acts = z((num_envs, max_players, 8), torch.uint8)
-            self._d_played, self._d_invalid, self._d_error = (z(num_envs, torch.uint8) for _ in range(3))
+            # per-step outputs rotate through three buffer sets: what step k returns is overwritten by step k + 2
+            # (needs_reset: written by step k, read by step k + 1 as `resetting` and handed out as info["reset"])
+            self._d_step = [{"reward": z(num_envs, torch.float64), "winner": z(num_envs, torch.int8), "turn": z(num_envs, torch.int64),
+                             "terminated": z(num_envs, torch.bool), "truncated": z(num_envs, torch.bool), "needs_reset": z(num_envs, torch.bool),
+                             "played": z(num_envs, torch.bool), "invalid": z(num_envs, torch.bool), "error": z(num_envs, torch.bool)}
+                            for _ in range(3)]
+            self._step_no = 0
             if self._via_kernels:   # pinned landing buffers for the default (numpy) mode
                 pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
                 self._h_obs = [pin((num_envs, 9, board_height, board_width), torch.float32) for _ in range(2)]
@@ -222,7 +228,8 @@ class GeneralsVecEnv:
 
     def _reset_device(self):
         self._d_turn.zero_()
-        self._d_needs_reset.zero_()
+        for b in self._d_step:
+            b["needs_reset"].zero_()
         obs = self._gym_observe()          # also stores the stats the first step's reward is measured against
         return obs, {"player_id": self.player_id, "valid_actions_mask": self.valid_actions_mask, "turn": self._d_turn.clone()}
 
@@ -231,24 +238,28 @@ class GeneralsVecEnv:
         if isinstance(actions, np.ndarray):
             actions = t.from_numpy(np.ascontiguousarray(actions, np.int64))
         actions = t.as_tensor(actions, dtype=t.int64).to(self._dev).reshape(self.num_envs).contiguous()
-        resetting = self._d_needs_reset.clone()
+        k = self._step_no
+        self._step_no += 1
+        cur, out = self._d_step[k % 3], self._d_step[(k + 1) % 3]
+        resetting = cur["needs_reset"]          # written by the previous step (or zeroed by reset)
         # opponents: the on-device random agent writes every slot; the learner's slot is then overwritten
         check(e.L.gvec_agent_actions(e.h, self._seed + 1000 * self._episode + 1, 0, self._d_acts.data_ptr(), 1), "gvec_agent_actions")
         self._episode += 1
         prev_mask = self._d_mask[self._obs_flip]
         check(e.L.gvec_gym_actions(e.h, self.player_id, actions.data_ptr(), prev_mask.data_ptr(), resetting.data_ptr(), self._d_acts.data_ptr(),
-                                   self._d_played.data_ptr(), self._d_invalid.data_ptr(), self._d_error.data_ptr()), "gvec_gym_actions")
+                                   out["played"].data_ptr(), out["invalid"].data_ptr(), out["error"].data_ptr()), "gvec_gym_actions")
         e.step_device(self._d_acts.data_ptr())     # aborted turns are the opponents' business, as over gRPC
-        rs, played = resetting.bool(), self._d_played.bool()
-        self._d_turn = t.where(rs, t.zeros_like(self._d_turn), self._d_turn + played.to(t.int64))
-        obs = self._gym_observe()
-        reward = t.where(rs, t.zeros_like(self._d_reward), t.where(played, self._d_reward, t.full_like(self._d_reward, -0.1)))
-        terminated = self._d_done.bool() & played & ~rs
-        truncated = (self._d_turn >= self.max_turns) & played & ~rs
-        self._d_needs_reset = (terminated | truncated).to(t.uint8)
-        info = {"turn": self._d_turn.clone(), "valid_actions_mask": self.valid_actions_mask, "invalid_action": self._d_invalid.bool(),
-                "error": self._d_error.bool(), "winner": t.where(terminated, self._d_winner, t.full_like(self._d_winner, -1)), "reset": rs}
-        return obs, reward, terminated, truncated, info
+        # observation, mask, reward and the step's bookkeeping (turn count, terminated / truncated / needs_reset) in one launch
+        self._obs_flip ^= 1
+        obs, mask = self._d_obs[self._obs_flip], self._d_mask[self._obs_flip]
+        check(e.L.gvec_gym_finish_step(e.h, self.player_id, self._d_turn.data_ptr(), self.max_turns, resetting.data_ptr(),
+                                       out["played"].data_ptr(), obs.data_ptr(), mask.data_ptr(), out["reward"].data_ptr(),
+                                       out["terminated"].data_ptr(), out["truncated"].data_ptr(), out["winner"].data_ptr(),
+                                       out["needs_reset"].data_ptr(), out["turn"].data_ptr()), "gvec_gym_finish_step")
+        self.valid_actions_mask = mask.view(t.bool)
+        info = {"turn": out["turn"], "valid_actions_mask": self.valid_actions_mask, "invalid_action": out["invalid"], "error": out["error"],
+                "winner": out["winner"], "reset": resetting}
+        return obs, out["reward"], out["terminated"], out["truncated"], info
 
     def _to_numpy(self, obs, info):
         """The device path's outputs as numpy arrays (default mode): observation and mask land in pinned buffers that

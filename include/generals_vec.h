@@ -317,6 +317,16 @@ int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
  *   GVEC_ACT_RESET_ENV; played / invalid / error [B] 0/1 outputs (any may be NULL). */
 int32_t gvec_gym_observe(gvec_handle* h, int32_t player, const int64_t* turn_count, int32_t max_turns,
                          float* obs, uint8_t* mask, double* reward, uint8_t* done, int8_t* winner);
+/* gvec_gym_observe plus the bookkeeping GeneralsEnv.step wraps around it (generals_env.py:226-259), in the same
+ * kernel: per env, with rs = resetting[env] (this step re-dealt it) and pl = played[env] (gvec_gym_actions accepted
+ * the action): turn_count := rs ? 0 : turn_count + pl (in place, and copied to turn_out); the observation uses the new
+ * count; reward := rs ? 0 : (pl ? _calculate_reward : -0.1); terminated := game over & pl & !rs; truncated :=
+ * turn_count >= max_turns & pl & !rs; needs_reset := terminated | truncated; winner := terminated ? GetWinner : -1.
+ * Outputs other than obs / mask may be NULL.  One launch instead of one launch and a dozen elementwise tensor ops. */
+int32_t gvec_gym_finish_step(gvec_handle* h, int32_t player, int64_t* turn_count, int32_t max_turns,
+                             const uint8_t* resetting, const uint8_t* played, float* obs, uint8_t* mask, double* reward,
+                             uint8_t* terminated, uint8_t* truncated, int8_t* winner, uint8_t* needs_reset,
+                             int64_t* turn_out);
 int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_actions, const uint8_t* mask,
                          const uint8_t* resetting, gvec_action* actions, uint8_t* played, uint8_t* invalid,
                          uint8_t* error);
