@@ -711,11 +711,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
   wave_lds_fence();
   {
     const int nbytes = 5 * A.stride;
-    if ((nbytes & 15) == 0) {  // the env's mask starts on a 16-byte boundary as well
+    if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(A.mask) & 15u) == 0u) {  // every env's mask starts on a 16-byte boundary
       const u32x4* s4 = reinterpret_cast<const u32x4*>(ms);
       u32x4* g4 = reinterpret_cast<u32x4*>(mask);
       for (int i = lane; i < (nbytes >> 4); i += 64) st_stream<GVEC_NT_MASK>(g4 + i, s4[i]);
-    } else if ((nbytes & 3) == 0) {
+    } else if ((nbytes & 3) == 0 && (reinterpret_cast<uintptr_t>(A.mask) & 3u) == 0u) {
       const uint32_t* s1 = reinterpret_cast<const uint32_t*>(ms);
       uint32_t* g1 = reinterpret_cast<uint32_t*>(mask);
       for (int i = lane; i < (nbytes >> 2); i += 64) st_stream<GVEC_NT_MASK>(g1 + i, s1[i]);

@@ -1045,6 +1045,10 @@ struct PBoard {
   // Needs larmy (NSLOT*64 dwords >= pstride*4*fd for MAXP <= 8); legal_env is 16-byte aligned (4*fd dwords per player).
   __device__ __forceinline__ void store_masks_staged(const uint32_t (&m)[NR][4], uint32_t* legal_env, int fd, int pstride) const {
     static_assert(MAXP <= 8, "the army shadow holds the mask block");
+    if ((reinterpret_cast<uintptr_t>(legal_env) & 15u) != 0u) {  // a caller's own mask buffer (gvec_step, device pointers) may sit anywhere
+      store_masks(m, legal_env, fd, pstride);
+      return;
+    }
     uint32_t* stage = reinterpret_cast<uint32_t*>(larmy);
     const bool in = col() < fd;
     wave_lds_fence();

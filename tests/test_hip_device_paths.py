@@ -54,6 +54,32 @@ def test_device_pointer_step_and_readback(g):
     assert dev.device_buffer(3) not in (None, 0)
 
 
+def test_mask_buffer_of_the_caller_may_sit_at_any_dword(g):
+    """gvec_step with device pointers writes the masks into the caller's buffer; the kernel's wide (16-byte) stores
+    must not assume more than the 4-byte alignment a uint32 array has."""
+    import torch
+    B, w, h, P = 64, 20, 20, 4
+    army, owner, typ, ws, hs, ps = H.gen_boards(3, [(w, h, P)] * B, w, h)
+    ora = O.OracleBatch(B, w, h, P)
+    ora.reset(army, owner, typ, ws, hs, ps)
+    engs = []
+    for off in (0, 4, 8, 12):
+        e = g.VecEngine(B, w, h, P, stream=torch.cuda.current_stream().cuda_stream)
+        e.reset(army, owner, typ, ws, hs, ps)
+        raw = torch.zeros(B * P * e.mask_bytes + 64, dtype=torch.uint8, device="cuda")
+        engs.append((e, raw, off))
+    for k in range(12):
+        acts = ora.agent_actions(6, 20)
+        oerr, obits = ora.step(acts, want_mask=True)
+        d_acts = torch.from_numpy(acts.view(np.uint8).reshape(-1).copy()).cuda()
+        for e, raw, off in engs:
+            assert raw.data_ptr() % 16 == 0
+            e.step_device(d_acts, None, raw.data_ptr() + off)
+            got = raw[off:off + B * P * e.mask_bytes].cpu().numpy().reshape(obits.shape)
+            assert np.array_equal(got, obits), (k, off)
+            assert not raw[:off].any() and not raw[off + B * P * e.mask_bytes:].any(), "nothing outside the buffer is written"
+
+
 def test_partial_reset_by_env_ids(g):
     B, w, h, P = 64, 10, 10, 2
     sizes = [(w, h, P)] * B
