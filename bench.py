@@ -2,7 +2,9 @@
 """bench.py — env-steps/s of the batched Generals.io turn engine on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` every process is one
+     rank; as a PLAIN command the parent - which never touches the GPU - starts the N ranks itself as child processes
+     with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank 0's JSON line)
 
 One *step* = one engine turn for every board of the batch: one launch of the HIP step
 kernel (on-device random agent sampling from the legal mask -> movement/combat ->
@@ -32,7 +34,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0  # what a float4 copy reaches on this part (same guide): the practical ceiling of any streaming kernel
 
 
 def algorithmic_bytes(w, h, p, mask=True):
@@ -126,12 +129,62 @@ def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
 
 
 def shard_plan(args, world, rank):
-    """-> (boards of this rank, boards of the whole job, "weak" | "strong")."""
+    """-> (boards of this rank, boards of the whole job, "weak" | "strong", first global env id of this rank)."""
     if args.total_envs > 0:
         from generalsreinforcementlearning_amd.sharding import shard_range
-        _, n = shard_range(args.total_envs, world, rank)
-        return n, args.total_envs, "strong"
-    return args.envs_per_gpu, args.envs_per_gpu * world, "weak"
+        begin, n = shard_range(args.total_envs, world, rank)
+        return n, args.total_envs, "strong", begin
+    return args.envs_per_gpu, args.envs_per_gpu * world, "weak", rank * args.envs_per_gpu
+
+
+def gather_slab_envs(args, world):
+    """Records per rank per gather: the same on every rank (dist.gather needs equal slabs), so it is bounded by the
+    SMALLEST shard - total // world under strong scaling with a total that does not divide."""
+    smallest = (args.total_envs // world) if args.total_envs > 0 else args.envs_per_gpu
+    return max(0, min(args.gather_envs, smallest))
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` as a plain command: this process has made no GPU call (torch is not even imported
+    yet) and starts the N ranks as fresh child processes - never an exec of a process that touched the GPU.  Rank 0's
+    stdout (the JSON line) is relayed; every other stream is inherited.  A rank that dies takes the others with it
+    (they would wait in the next barrier forever): exact PIDs only."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                rc = bad[0].returncode
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.05)
+        out = procs[0].stdout.read() if procs[0].stdout else ""
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
 
 
 class _NullEngine:
@@ -169,11 +222,13 @@ def rehearse_cpu(args):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if os.environ.get("GVEC_BENCH_FAIL_RANK") == str(rank):   # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
-    B, total, mode = shard_plan(args, world, rank)
+    B, total, mode, env_base = shard_plan(args, world, rank)
     eng = _NullEngine(64)
-    ge = min(args.gather_envs, B)
+    ge = gather_slab_envs(args, world)
     rg = RecordGather(ge * eng.experience_record_bytes(), torch.device("cpu"), dst=0) if ge > 0 else None
     got = 0
     for k in range(args.warmup):
@@ -187,7 +242,7 @@ def rehearse_cpu(args):
             eng.experience_begin_range(0, ge)
         eng.rollout(1, args.seed, 0, fused=False, want_stats=False)
         if gathering:
-            eng.experience_records(rg.send.data_ptr(), None, 0, ge, rank * B)
+            eng.experience_records(rg.send.data_ptr(), None, 0, ge, env_base)
             rg.send.fill_((rank * 31 + k) % 251)
             out = rg.gather()
             if rank == 0:
@@ -199,7 +254,7 @@ def rehearse_cpu(args):
     if rank == 0:
         print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathers": got,
                           "value": total * args.steps / float(t.item()), "scaling": mode, "total_envs": total,
-                          "envs_rank0": B}), flush=True)
+                          "envs_rank0": B, "gather_envs_per_rank": ge}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -239,6 +294,10 @@ def main():
                          "used by tests/test_bench_distributed.py; prints a line marked \"rehearsal\": true, never a result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: no launcher made the ranks, so this (GPU-less) process does
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     if args.rehearse_cpu:
         return rehearse_cpu(args)
@@ -248,7 +307,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher made WORLD_SIZE={world} ranks")
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -269,7 +328,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     W, H, P = args.width, args.height, args.players
-    B, total_envs, scaling = shard_plan(args, world, rank)
+    B, total_envs, scaling, env_base = shard_plan(args, world, rank)
     eng = g.VecEngine(B, W, H, P, fog_of_war=bool(args.fog), device=local_rank, auto_reset=True, stream=stream.cuda_stream)
     if args.mixed:
         import numpy as np
@@ -290,8 +349,8 @@ def main():
         # internal/grpc/gameserver/stream_aggregator.go:75-155), expanded there (experience.decode_records).
         # Two slabs alternate so step k+1's records never wait for step k's gather on the side stream.
         from generalsreinforcementlearning_amd.sharding import RecordGather
-        ge = min(args.gather_envs, B)
-        rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)]
+        ge = gather_slab_envs(args, world)
+        rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)] if ge > 0 else None
         slab_free = [None, None]
         side = torch.cuda.Stream()
 
@@ -300,7 +359,6 @@ def main():
     def one_step(k):
         gathering = rgs is not None and k % K == K - 1
         if gathering:
-            ge = min(args.gather_envs, B)
             lo = ((k // K) * ge) % max(1, B - ge + 1)
             eng.experience_begin_range(lo, ge)                    # captureStateForExperience for the sampled slice
             eng.record_agent_actions(True)                        # the record needs the moves the device agent plays in this step
@@ -310,7 +368,7 @@ def main():
             i = (k // K) & 1
             if slab_free[i] is not None:
                 stream.wait_event(slab_free[i])                   # slab i was last read by the gather before the previous one
-            eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, rank * B)   # compute stream, after this step's kernel
+            eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, env_base)   # compute stream, after this step's kernel
             if args.gather_mode == 1:
                 return
             if args.gather_mode == 2:
@@ -339,6 +397,8 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     sync_all()
+    played0 = eng.counters()          # H_CNT_* summed over the boards: one reduction launch + read-back, outside the events
+    sync_all()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
@@ -348,10 +408,15 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # HIP events on the launch stream
+    played1 = eng.counters()
+    played = {k: played1[k] - played0[k] for k in played1}   # turns the engines actually played inside the timed region
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        c = torch.tensor([played["env_steps"], played["aborted_turns"], played["games_finished"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        played = dict(zip(("env_steps", "aborted_turns", "games_finished"), (int(v) for v in c.tolist())))
 
     fused = None
     if not args.no_fused:
@@ -369,22 +434,33 @@ def main():
     gathered = None
     if rgs is not None and rank == 0:
         # the consumer side, outside the timed region: expand the last gathered slabs into Experience fields
+        import bisect
         from generalsreinforcementlearning_amd.experience import decode_records
         torch.cuda.synchronize()
         lay = eng.experience_record_layout()
         n_g = (args.warmup + args.steps) // K                      # gathers so far; the last one filled slab (n_g - 1) & 1
         last = rgs[(n_g - 1) & 1].recv if n_g > 0 else []
         decs = [decode_records(t.cpu().numpy(), lay, drop_invalid=True) for t in last]
-        gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_gather": min(args.gather_envs, B),
+        begins = [shard_plan(args, world, r)[3] for r in range(world)]   # first global env id of every rank
+        gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_gather": ge,
                     "gather_every_steps": K,
                     "experiences_decoded_last_step": int(sum(len(d["env"]) for d in decs)),
-                    "ranks_seen": sorted({int(e) // B for d in decs for e in d["env"]})}
+                    "ranks_seen": sorted({bisect.bisect_right(begins, int(e)) - 1 for d in decs for e in d["env"]})}
     if rank == 0:
         n = world
+        kernel_s = kernel_ms / 1e3
+        # roofline.frac: the bytes one env-step MUST move by construction of the resident layout (header, mutable +
+        # constant planes in, header + mutable planes out, narrow armies both ways, the legal masks out) - from the
+        # library's own layout constants (gvec_step_traffic_bytes), never hard-coded - over the kernel's time over peak.
+        tb = eng.step_traffic_bytes()
+        comp = tb["read"] + tb["write"] + tb["mask"]
+        achieved = comp * B / kernel_s / 1e9
+        # contract_*: SURVEY 8(d)'s ALGORITHMIC bytes (8 B per tile each way with int32 armies and every list stored):
+        # the kernel moves about 62 % of them, so this figure can pass 1 and is kept for comparison only.
         abytes = algorithmic_bytes(W, H, P, True)
-        achieved = abytes * B / (kernel_ms / 1e3) / 1e9
-        # HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel build (profiles/pmc_traffic.json carries the
-        # hash of the kernel sources it was measured on; a figure from another build is dropped, not reported)
+        contract = abytes * B / kernel_s / 1e9
+        # traffic: HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel build (profiles/pmc_traffic.json carries
+        # the hash of the kernel sources it was measured on; a figure from another build is dropped, not reported)
         traffic, traffic_note = None, "no PMC record for this kernel build"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -398,31 +474,40 @@ def main():
                     else f"{B} boards/GPU (weak scaling)")
         if args.mixed:
             mode_txt += " MIXED 10x10/15x15/20x20 boards with 2-4 players padded to"
+        launches = total_envs * args.steps
         out = {
             "metric": "env steps/sec (whole node), 20x20 4P fog-on; state bit-exact vs the C restatement of the Go engine "
                       "(the reference's own test vectors pass on both)",
-            "value": total_envs * args.steps / elapsed,
+            # value counts the turns the engines actually PLAYED in the timed region (the device's own H_CNT_STEPS counters,
+            # summed over every board and rank): a step that re-deals a finished board plays no turn and is not counted
+            "value": played["env_steps"] / elapsed,
             "unit": "env-steps/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic", "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
+            "env_steps_played": played["env_steps"], "board_launches": launches,
+            "played_fraction": played["env_steps"] / max(1, launches),
+            "aborted_turns": played["aborted_turns"], "games_finished": played["games_finished"],
+            "board_launches_per_s": launches / elapsed,
             "config": {"workload": f"{mode_txt} x {W}x{H} {P}P fog-{'on' if args.fog else 'off'} + legal mask, on-device random "
                                    f"agent, auto-reset pool {args.pool}, 1 turn per launch",
                        "envs_per_gpu": B, "total_envs": total_envs, "board": [W, H, P], "parallelism": f"env-sharded x{n}",
-                       "gather_envs_per_step": (args.gather_envs if rgs is not None else 0),
+                       "gather_envs_per_step": (ge if rgs is not None else 0),
                        "gather_every_steps": (K if rgs is not None else 0)},
-            # achieved / frac: ALGORITHMIC bytes over the kernel's measured time - the contract's figure.
-            # traffic_*: the bytes the kernel really moves (PMC), when a record for this build exists.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "traffic_gbs": (traffic / (kernel_ms / 1e3) / 1e9 if traffic else None),
-                         "traffic_frac": (traffic / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS if traffic else None),
-                         "kernel": step_kernel_name(W, H, P), "algorithmic_bytes_per_env_step": abytes,
+                         "traffic_gbs": (traffic / kernel_s / 1e9 if traffic else None),
+                         "traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS if traffic else None),
+                         "copy_peak": HBM_COPY_GBS, "copy_frac": achieved / HBM_COPY_GBS,
+                         "contract_bytes_per_env_step": abytes, "contract_gbs": contract, "contract_frac": contract / HBM_PEAK_GBS,
+                         "kernel": step_kernel_name(W, H, P), "bytes_per_env_step": comp, "bytes_breakdown": tb,
                          "units_per_launch": B, "kernel_ms": kernel_ms,
-                         "note": "achieved / frac price SURVEY 8(d)'s ALGORITHMIC bytes (8 B per tile each way, int32 armies): the kernel "
-                                 "stores armies as u16 and lists on demand and moves about 64 % of them, so frac can pass 1; "
-                                 "traffic_frac is the HBM's own utilisation (PMC bytes of this build / kernel time / peak)"},
+                         "note": "achieved / frac: bytes the step kernel must move by construction of its resident layout "
+                                 "(bytes_breakdown: read + write + mask per env-step, from gvec_step_traffic_bytes) x boards per launch / "
+                                 "kernel time (HIP events on the launch stream) / 8 TB/s spec peak; copy_frac: the same over the 6.29 TB/s a "
+                                 "float4 copy reaches on this part; traffic*: PMC-measured HBM bytes of this build; contract_*: SURVEY 8(d)'s "
+                                 "7,280-B algorithmic figure (int32 armies, lists always stored), which this kernel undercuts - it can pass 1"},
         }
         if gathered:
             out["experience_gather"] = gathered

@@ -28,7 +28,7 @@ class StateView(C.Structure):
 
 
 class RolloutStats(C.Structure):
-    _fields_ = [("env_steps", C.c_int64), ("aborted_turns", C.c_int64), ("games_finished", C.c_int64), ("captures", C.c_int64)]
+    _fields_ = [("env_steps", C.c_int64), ("aborted_turns", C.c_int64), ("games_finished", C.c_int64), ("reserved", C.c_int64)]
 
 
 # every symbol include/generals_vec.h declares: (restype, argtypes)
@@ -56,6 +56,8 @@ SYMBOLS = {
     "gvec_rollout": (_i32, [_vp, _i32, _u64, _i32, _i32, C.POINTER(RolloutStats)]),
     "gvec_set_agent_mix": (_i32, [_vp, _i32, _i32]),
     "gvec_agent_actions": (_i32, [_vp, _u64, _i32, _vp, _i32]),
+    "gvec_counters": (_i32, [_vp, C.POINTER(RolloutStats)]),
+    "gvec_step_traffic_bytes": (_i32, [_vp, C.POINTER(C.c_int64)]),
     "gvec_experience_begin": (_i32, [_vp]),
     "gvec_experience_begin_range": (_i32, [_vp, _i32, _i32]),
     "gvec_experience_rewards": (_i32, [_vp, _vp, _vp, _i32]),

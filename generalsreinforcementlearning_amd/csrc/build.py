@@ -17,7 +17,8 @@ ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libgvec_hip.so")
 SRCS = ["gvec_kernels.hip", "gvec_api.hip"]
 DEPS = ["gvec_device.hpp", "gvec_packed.hpp", "gvec_launch.hpp", os.path.join(ROOT, "include", "generals_vec.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-save-temps=obj"]  # keeps build/*-gfx950.s: tests/test_kernel_asm.py scans the generated ISA
 
 
 def _newer(target, sources):
@@ -48,6 +49,10 @@ def build(force=False, verbose=True):
                     raise RuntimeError("hipcc failed: " + " ".join(r.args))
                 if verbose and r.stderr.strip():
                     sys.stderr.write(r.stderr)
+        # -save-temps leaves ~60 MB of preprocessed sources and bitcode beside the objects: only the gfx950 ISA is kept
+        for f in os.listdir(os.path.join(HERE, "build")):
+            if f.endswith((".hipi", ".bc", ".out", ".resolution.txt", ".hipfb")) or f.endswith("x86_64-unknown-linux-gnu.s"):
+                os.unlink(os.path.join(HERE, "build", f))
     if jobs or force or _newer(OUT, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -679,7 +679,7 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
     stats->env_steps = (int64_t)(c[3] - c[0]);
     stats->aborted_turns = (int64_t)(c[4] - c[1]);
     stats->games_finished = (int64_t)(c[5] - c[2]);
-    stats->captures = 0;
+    stats->reserved = 0;
   }
   return GVEC_OK;
 }
@@ -692,6 +692,38 @@ int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_
   }
   h->agent_noop = (uint32_t)noop_per_65536;
   h->agent_half = (uint32_t)half_per_65536;
+  return GVEC_OK;
+}
+
+int32_t gvec_counters(gvec_handle* h, gvec_rollout_stats* out) {
+  if (!h || !out) return GVEC_E_INVALID;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, 3 * sizeof(unsigned long long), h->stream));
+  HIPCHK(launch_counter_sum(h->d_hdr, h->cfg.num_envs, h->d_counters, h->stream));
+  unsigned long long c[3];
+  HIPCHK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  out->env_steps = (int64_t)c[0];
+  out->aborted_turns = (int64_t)c[1];
+  out->games_finished = (int64_t)c[2];
+  out->reserved = 0;
+  return GVEC_OK;
+}
+
+int32_t gvec_step_traffic_bytes(const gvec_handle* h, int64_t* out4) {
+  if (!h || !out4) return GVEC_E_INVALID;
+  static_assert(Planes<4>::MUTABLE == 2 * 4 + 3 && Planes<4>::LST - Planes<4>::MUTABLE == 10 && Planes<4>::COUNT - Planes<4>::LST == 4,
+                "gvec_step_traffic_bytes restates the plane block's partition");
+  const int64_t fd = h->fd, mp = h->var.maxp;
+  const int64_t hdr = HDR_DW * 4;
+  const int64_t mut = (2 * mp + 3) * fd * 4;    // Planes<MAXP>::MUTABLE: own, vis, chg, vch, gt1
+  const int64_t cst = 10 * fd * 4;              // gen, city, mtn, valid, ncol0, ncolL, ok[4]
+  const int64_t lst = mp * fd * 4;              // OwnedTiles planes: only while HF_LDIFF
+  const int64_t a16 = (int64_t)h->army_dw * 2, a32 = (int64_t)h->army_dw * 4;
+  out4[0] = hdr + mut + cst + a16;
+  out4[1] = hdr + mut + a16;
+  out4[2] = (int64_t)h->maxp * h->mask_bytes;
+  out4[3] = 2 * lst + 2 * a32;
   return GVEC_OK;
 }
 

@@ -76,8 +76,11 @@ __device__ __forceinline__ void st_through(uint16_t* p, uint16_t v) {
   asm volatile("global_store_short %0, %1, off sc1 nt" : : "v"(p), "v"((uint32_t)v) : "memory");
 }
 __device__ __forceinline__ void st_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory"); }
+// gfx940-family hazard: a VMEM store of more than 64 bits needs 2 wait states before a VALU write of its data
+// registers, and the compiler's hazard recognizer cannot see a store inside an asm string: `s_nop 1` (= 2 wait
+// states) is the only protection.  tests/test_kernel_asm.py scans the generated code for every such store.
 __device__ __forceinline__ void st_through(u32x4* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <int CLASS, typename T>
 __device__ __forceinline__ void st_stream(T* p, T v) {

@@ -199,6 +199,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, step_waves(MAXP, NSLOT)) void
   uint32_t err = 0u;
   bool types_dirty = false, changed = true;
   const bool can_redeal = (A.flags & KF_AUTORESET) && A.pool_size > 0;
+  if (AGENT && A.actions_out && (b.hflags & HF_DONE)) {
+    // a re-dealt or frozen env plays no move in this launch: its recorded actions are "none", not whatever an
+    // earlier recorded step left in the buffer (gvec_experience_records builds acted bits from these words)
+    if (lane < A.pstride) reinterpret_cast<uint2*>(A.actions_out)[(size_t)env * A.pstride + lane] = make_uint2(0u, 0u);
+  }
   if (can_redeal && ((b.hflags & HF_DONE) || force_redeal)) {
     redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);  // the pool board brings its own gt1 plane
     types_dirty = true;

@@ -84,7 +84,7 @@ def state_to_tensor(owner_planes, vis_plane, gen, city, mtn, army, player, fog, 
     return out.reshape(9, h, w)
 
 
-def decode_records(slab, layout, drop_invalid=False):
+def decode_records(slab, layout, drop_invalid=True):
     """slab: uint8 / uint32 array holding k records back to back (host memory).  Returns the batch dict of
     VecExperienceCollector.after_step (one entry per (record, player) that acted, record-major), plus
     "env" = the record's env id and "valid" (False: the env was re-dealt since the snapshot, its transition is void)."""

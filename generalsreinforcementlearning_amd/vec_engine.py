@@ -196,6 +196,18 @@ class VecEngine:
         (0, 0) always plays a full move, uniform over the legal ones."""
         check(self.L.gvec_set_agent_mix(self.h, int(noop_per_65536), int(half_per_65536)), "gvec_set_agent_mix")
 
+    def counters(self):
+        """Lifetime counters summed over all envs: turns actually played, aborted turns (H5), games finished."""
+        st = RolloutStats()
+        check(self.L.gvec_counters(self.h, C.byref(st)), "gvec_counters")
+        return {"env_steps": st.env_steps, "aborted_turns": st.aborted_turns, "games_finished": st.games_finished}
+
+    def step_traffic_bytes(self):
+        """Bytes one env-step must move by construction of the resident layout: dict(read, write, mask, rare_extra)."""
+        out = (C.c_int64 * 4)()
+        check(self.L.gvec_step_traffic_bytes(self.h, out), "gvec_step_traffic_bytes")
+        return {"read": out[0], "write": out[1], "mask": out[2], "rare_extra": out[3]}
+
     def agent_actions(self, seed, invalid_permille=0):
         acts = np.zeros((self.B, self.max_p), ACTION_DTYPE)
         check(self.L.gvec_agent_actions(self.h, seed, invalid_permille, _ptr(acts), MEM_HOST), "gvec_agent_actions")

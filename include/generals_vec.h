@@ -143,7 +143,7 @@ typedef struct gvec_rollout_stats {
   int64_t env_steps;     /* turns actually advanced (live envs x turns)                 */
   int64_t aborted_turns; /* turns that returned a move-validation error     */
   int64_t games_finished;
-  int64_t captures;      /* reserved                                                    */
+  int64_t reserved;      /* always 0 (keeps the struct at 32 bytes)                        */
 } gvec_rollout_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------- */
@@ -242,6 +242,19 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed,
  * the legal ones.  The default acts three times as often as the Go helper: more work per turn.
  * Applies to gvec_rollout and gvec_agent_actions. */
 int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_per_65536);
+/* Lifetime counters summed over every env of the handle (absolute values; gvec_rollout's stats are the
+ * difference of two such reads): env_steps = engine turns actually PLAYED - a step that re-deals a finished
+ * env, a frozen env or a GVEC_ACT_SKIP_ENV env plays none -, aborted_turns, games_finished.
+ * One small reduction launch + an 24-byte read-back; synchronises the handle's stream. */
+int32_t gvec_counters(gvec_handle* h, gvec_rollout_stats* out);
+/* The HBM bytes ONE env-step of the hot path (gvec_step / per-turn gvec_rollout) must move BY CONSTRUCTION of the
+ * resident layout, from the same constants the kernel is compiled with:
+ * out4[0] read  = header + mutable and constant planes + narrow armies
+ * out4[1] write = header + mutable planes + narrow armies
+ * out4[2] mask  = the legal masks written when legal_bits / the agent is on (max_players * mask_bytes)
+ * out4[3] extra = what an env in the rare forms adds on top (list planes both ways + the int32 army escape both ways)
+ * bench.py prices roofline.frac with read + write + mask. */
+int32_t gvec_step_traffic_bytes(const gvec_handle* h, int64_t* out4);
 /* The agent alone: fills actions[B][max_players] for the current state/turn. */
 int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille,
                            gvec_action* actions, int32_t mem);

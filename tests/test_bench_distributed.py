@@ -57,3 +57,39 @@ def test_bench_refuses_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _plain_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_plain_command_line_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's single-GPU line): the parent,
+    which never touches the GPU, starts the ranks itself and relays rank 0's ONE JSON line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--envs-per-gpu", "256", "--gather-envs", "16", "--gather-every", "2", "--rehearse-cpu"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=_plain_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 4 and d["gathers"] == 2 and d["total_envs"] == 512
+
+
+def test_bench_plain_command_line_strong_scaling_with_a_total_that_does_not_divide():
+    """2,049 boards over 2 ranks: shards of 1,025 and 1,024; every rank gathers the same slab (bounded by the smallest
+    shard) and tags its records with its shard's first global env id."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+                        "--total-envs", "2049", "--gather-envs", "4096", "--gather-every", "1", "--rehearse-cpu"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=_plain_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["envs_rank0"] == 1025 and d["gather_envs_per_rank"] == 1024 and d["gathers"] == 3
+
+
+def test_bench_plain_command_line_propagates_a_rank_failure():
+    """A rank that dies must not leave the others waiting in a barrier: the parent ends them and returns non-zero."""
+    env = dict(_plain_env(), GVEC_BENCH_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+                        "--envs-per-gpu", "64", "--rehearse-cpu"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0

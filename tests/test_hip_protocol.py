@@ -1,0 +1,110 @@
+"""SURVEY.md 8(d)'s parity protocol at BASELINE.json's sizes (BASELINE.md "Parity gate"): seeds {1, 2, 3}, 500 turns each,
+on-device random agent with deliberately invalid moves (H5 fires: `invalid_permille` >= 5), finished games re-dealt from a
+board pool, one kernel launch per turn (the benchmarked path: step_kernel<..., AGENT=true>), the oracle stepped beside it
+with its own agent and pool (same counter RNG, keyed by env id):
+
+  configs[1]  4,096 x 10x10 2P fog-off   ALL envs compared with the oracle after EVERY turn
+  configs[2]  65,536 x 15x15 2P fog-on   a 4,096-env subset compared after EVERY turn (+ its legal masks every 25 turns),
+                                         then every env of a fused 500-turn rollout == the per-turn rollout
+  configs[3]  262,144 x 20x20 4P fog-on  (the 8-GPU configuration's workload on one GPU) the subset every 25 turns; seed 1
+                                         also checks fused == per-turn over all 262,144 envs
+
+"Compared" = H.assert_states_equal: every tile plane (army, owner, type, visible, listed, changed, vis_changed), turn,
+done, winner, sizes, alive / army_count / tile_count per player, general_idx by contract.  All through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import _harness as H
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = (1, 2, 3)
+TURNS = 500
+THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def g():
+    import generalsreinforcementlearning_amd as g
+    return g
+
+
+def _pair(g, B, sub, w, h, p, fog, seed, pool):
+    """A HIP engine of B envs and an oracle of its first `sub` envs, both dealt the same boards and pool."""
+    eng = g.VecEngine(B, w, h, p, fog_of_war=fog, auto_reset=True)
+    eng.reset_generated(1000 + seed)
+    eng.build_board_pool(pool, 7000 + seed)
+    first = eng.game_state(0, sub)
+    ora = O.OracleBatch(sub, w, h, p, fog=fog)
+    ora.reset(first["army"], first["owner"], first["type"], first["width"], first["height"], first["players"])
+    ora.set_pool(pool, 7000 + seed)
+    H.assert_states_equal(first, ora.read_state(), "after reset")
+    return eng, ora
+
+
+def _lockstep(eng, ora, sub, seed, permille, every, mask_every, ctx):
+    aborted = 0
+    for k in range(TURNS):
+        eng.rollout(1, seed, permille, fused=False, want_stats=False)      # ONE step-kernel launch over all B envs
+        ora.rollout(1, seed, permille, threads=THREADS)
+        if (k + 1) % every == 0 or k == TURNS - 1:
+            H.assert_states_equal(eng.game_state(0, sub), ora.read_state(), f"{ctx} seed {seed} after turn {k + 1}")
+        if mask_every and ((k + 1) % mask_every == 0 or k == TURNS - 1):
+            assert np.array_equal(eng.legal_action_mask_bits()[:sub], ora.legal_mask(threads=THREADS)), f"{ctx} seed {seed} masks after turn {k + 1}"
+    c = eng.counters()
+    assert c["aborted_turns"] > 0, "no turn was aborted: H5 was not exercised"
+    return c
+
+
+def _fused_equals_per_turn(g, eng, B, w, h, p, fog, seed, permille, pool):
+    """A second engine plays the same 500 turns inside ONE launch (board in registers / LDS): every env must match."""
+    fus = g.VecEngine(B, w, h, p, fog_of_war=fog, auto_reset=True)
+    fus.reset_generated(1000 + seed)
+    fus.build_board_pool(pool, 7000 + seed)
+    fus.rollout(TURNS, seed, permille, fused=True, want_stats=False)
+    for lo in range(0, B, 32768):
+        n = min(32768, B - lo)
+        s1, s2 = eng.game_state(lo, n), fus.game_state(lo, n)
+        for f in s1:
+            assert np.array_equal(s1[f], s2[f]), f"fused vs per-turn: field {f} differs in envs [{lo}, {lo + n})"
+    assert fus.counters() == eng.counters()
+    fus.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_config1_4096x10x10_fog_off_all_envs_every_turn(g, seed):
+    B, w, h, p = 4096, 10, 10, 2
+    eng, ora = _pair(g, B, B, w, h, p, False, seed, pool=512)
+    c = _lockstep(eng, ora, B, seed, permille=8, every=1, mask_every=25, ctx="configs[1]")
+    assert c["env_steps"] > 0.9 * B * TURNS
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_config2_65536x15x15_subset_every_turn_then_all_envs_fused(g, seed):
+    B, sub, w, h, p = 65536, 4096, 15, 15, 2
+    eng, ora = _pair(g, B, sub, w, h, p, True, seed, pool=1024)
+    _lockstep(eng, ora, sub, seed, permille=6, every=1, mask_every=25, ctx="configs[2]")
+    _fused_equals_per_turn(g, eng, B, w, h, p, True, seed, 6, pool=1024)
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_config3_262144x20x20_4p_subset_every_25_turns(g, seed):
+    B, sub, w, h, p = 262144, 4096, 20, 20, 4
+    eng, ora = _pair(g, B, sub, w, h, p, True, seed, pool=4096)
+    _lockstep(eng, ora, sub, seed, permille=5, every=25, mask_every=0, ctx="configs[3]")
+    # the masks of the subset once: gvec_legal_mask into a device tensor, only the subset crosses PCIe (all of it is 218 MB)
+    import torch
+    from generalsreinforcementlearning_amd._lib import check
+    bits = torch.empty((B, p, eng.mask_bytes), dtype=torch.uint8, device="cuda")
+    check(eng.L.gvec_legal_mask(eng.h, bits.data_ptr(), 1), "gvec_legal_mask")
+    eng.synchronize()
+    assert np.array_equal(bits[:sub].cpu().numpy(), ora.legal_mask(threads=THREADS))
+    del bits
+    if seed == 1:
+        _fused_equals_per_turn(g, eng, B, w, h, p, True, seed, 5, pool=4096)
+    eng.close()
