@@ -317,11 +317,16 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if os.environ.get("GVEC_BENCH_DIST_INIT") == "gloo":
-            # diagnostics (with --gather-envs 0): an RCCL communicator, however and whenever it is created, slows the step
-            # kernel by 5-7 % on this stack (0.215 -> 0.226-0.234 ms at world size 1, kernel time by HIP events); gloo does not
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo")   # diagnostics only (scripts/rccl_tax.sh)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        # RCCL builds a communicator's channels and loads its kernels at the FIRST collective: ~16 ms during which the GPU
+        # sits idle.  Rounds 1-2 paid that inside the barrier that brackets the timed region and then measured the clock
+        # ramp that follows an idle gap (first 50 launches 270 us, next 50 235 us, then the plain 220 us:
+        # profiles/r03_rccl_tax.json) - the "5-7 % RCCL tax" of DESIGN.md section 8.  Pay it here, before the
+        # clock-settle phase; the bracketing barriers are then ~20 us collectives.
+        dist.barrier()
+        torch.cuda.synchronize()
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -353,6 +358,13 @@ def main():
         rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)] if ge > 0 else None
         slab_free = [None, None]
         side = torch.cuda.Stream()
+        if rgs is not None:
+            # the gather's send/recv channels connect lazily too: one untimed gather per slab, on the side stream it will use
+            with torch.cuda.stream(side):
+                for rg_ in rgs:
+                    rg_.send.zero_()
+                    rg_.gather()
+            torch.cuda.synchronize()
 
     K = max(1, args.gather_every)
 
