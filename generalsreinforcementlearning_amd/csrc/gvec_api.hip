@@ -942,6 +942,49 @@ int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_acti
   return GVEC_OK;
 }
 
+int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const int64_t* gym_actions, const uint8_t* resetting,
+                      int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask, double* reward, uint8_t* terminated,
+                      uint8_t* truncated, int8_t* winner, uint8_t* needs_reset, int64_t* turn_out, uint8_t* played, uint8_t* invalid,
+                      uint8_t* error) {
+  if (!h || !gym_actions || !resetting || !turn_count || !obs || !mask || player < 0 || player >= h->maxp || max_turns < 1) return GVEC_E_INVALID;
+  if (!(h->cfg.auto_reset && h->pool_size > 0)) {
+    set_err("gvec_gym_step needs auto_reset and a board pool (gvec_build_board_pool): episodes end by re-dealing");
+    return GVEC_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->d_gym_prev) {
+    HIPCHK(hipMalloc(&h->d_gym_prev, (size_t)h->cfg.num_envs * 3 * h->var.maxp * 4));
+    HIPCHK(hipMemsetAsync(h->d_gym_prev, 0, (size_t)h->cfg.num_envs * 3 * h->var.maxp * 4, h->stream));
+  }
+  StepArgs a = base_args(h);
+  a.seed_lo = (uint32_t)agent_seed;
+  a.seed_hi = (uint32_t)(agent_seed >> 32);
+  a.invalid_permille = 0;
+  GymStepArgs g;
+  memset(&g, 0, sizeof g);
+  g.gym_actions = gym_actions;
+  g.resetting = resetting;
+  g.turn_io = turn_count;
+  g.turn_out = turn_out;
+  g.obs = obs;
+  g.mask = mask;
+  g.reward = reward;
+  g.terminated = terminated;
+  g.truncated = truncated;
+  g.winner = winner;
+  g.needs_reset = needs_reset;
+  g.played = played;
+  g.invalid = invalid;
+  g.error = error;
+  g.prev_stats = h->d_gym_prev;
+  g.stride = h->stride;
+  g.player = player;
+  g.max_turns = max_turns;
+  HIPCHK(launch_gym_step(h->var, a, g, h->stream));
+  h->legal_valid = false;  // the engine's own mask buffer was not refreshed
+  return GVEC_OK;
+}
+
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
   if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
   HIPCHK(hipSetDevice(h->cfg.device));

@@ -647,6 +647,110 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void observe_kernel(Experienc
 // NORMAL / owner -1 / army 0; a fogged tile keeps its type, hides owner and army.  A hidden tile is a normal
 // tile by definition (visibility_optimized.go:189-191), so the shown type is always the real one).
 // =========================================================================================
+// The observation and mask of one env, from replicated flat planes (row 0 is read) of either board layout: `seen` what
+// the proto shows as visible, own_p / own_any the learner's and anybody's tiles, m0..m3 the four direction planes of
+// _get_valid_actions_mask and `many` their OR (index 4: "a half move is valid iff a full move is").  ms: this wave's
+// LDS stage of (NSLOT*64*5 + 15)/16*16 bytes.
+template <int NSLOT, typename BT>
+__device__ __forceinline__ void gym_emit(const BT& b, uint32_t seen, uint32_t own_p, uint32_t own_any, uint32_t m0, uint32_t m1, uint32_t m2,
+                                         uint32_t m3, uint32_t many, float tc, float* obs, uint8_t* mask, uint8_t* ms, int stride) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int t = 64 * s + lane;
+    const bool vis = b.gather(seen, s) != 0u, mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u;
+    const bool g = b.gather(b.gen, s) != 0u, c = b.gather(b.city, s) != 0u, mt = b.gather(b.mtn, s) != 0u;
+    const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
+    const int32_t army = vis ? b.army[s] : 0;                                    // hidden and fogged tiles: army 0
+    // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
+    const float la = (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
+    if (t < stride) {
+      const bool in = t < b.N;
+      const size_t n = (size_t)stride;
+      st_stream<GVEC_NT_MASK>(obs + 0 * n + t, (in && vis) ? 1.0f : 0.0f);                                // :312-314
+      st_stream<GVEC_NT_MASK>(obs + 1 * n + t, (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f));   // :316-322 (owner -1 unless visible)
+      st_stream<GVEC_NT_MASK>(obs + 2 * n + t, in ? la : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 3 * n + t, (in && !g && !c && !mt) ? 1.0f : 0.0f);                    // :328-336 one-hot type
+      st_stream<GVEC_NT_MASK>(obs + 4 * n + t, (in && mt) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 5 * n + t, (in && c) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 6 * n + t, (in && g) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(obs + 7 * n + t, tc);                                                       // the whole plane, like obs[7, :, :] = ...
+      st_stream<GVEC_NT_MASK>(obs + 8 * n + t, 0.0f);                                                     // left zero by the reference (:341-343)
+      uint8_t* mk = ms + t * 5;
+      mk[0] = (uint8_t)k0;
+      mk[1] = (uint8_t)k1;
+      mk[2] = (uint8_t)k2;
+      mk[3] = (uint8_t)k3;
+      mk[4] = (uint8_t)k4;
+    }
+  }
+  wave_lds_fence();
+  // the mask is five bytes per tile: laid out in LDS above and stored as whole 16-byte (or 4-byte) pieces of consecutive
+  // lanes - five byte stores per lane and slot, each lane 5 bytes from its neighbour, held this kernel at 1.4 TB/s
+  const int nbytes = 5 * stride;
+  if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15u) == 0u) {
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ms);
+    u32x4* g4 = reinterpret_cast<u32x4*>(mask);
+    for (int i = lane; i < (nbytes >> 4); i += 64) st_stream<GVEC_NT_MASK>(g4 + i, s4[i]);
+  } else if ((nbytes & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3u) == 0u) {
+    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(ms);
+    uint32_t* g1 = reinterpret_cast<uint32_t*>(mask);
+    for (int i = lane; i < (nbytes >> 2); i += 64) st_stream<GVEC_NT_MASK>(g1 + i, s1[i]);
+  } else {
+    for (int i = lane; i < nbytes; i += 64) mask[i] = ms[i];
+  }
+}
+
+// _calculate_reward (generals_env.py:499-561) against the stats the previous call stored, GeneralEnv.step's bookkeeping
+// around it (:226-259) when `flow`, then the new stats.  cur_tc / cur_ac: the learner's tile_count (= len(OwnedTiles),
+// server.go:536) and ArmyCount; tcl / acl: lane p < MAXP holds player p's.  Every lane calls it.
+struct GymFlowOut {
+  double* reward;
+  uint8_t* done;
+  int8_t* winner;
+  int64_t* turn_io;
+  int64_t* turn_out;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  uint8_t* needs_reset;
+};
+template <int MAXP>
+__device__ __forceinline__ void gym_bookkeeping(int env, int pl, int P, uint32_t alive, bool over, int32_t cur_tc, int32_t cur_ac, uint32_t tcl,
+                                                uint32_t acl, int32_t* prev, bool flow, bool rs, bool pl_ok, int64_t turns, int max_turns,
+                                                const GymFlowOut& O) {
+  const int lane = lane_id();
+  const int na = __builtin_popcount(alive);
+  const int winner = (over && P > 1 && na == 1) ? (31 - __builtin_clz(alive)) : -1;   // Engine.GetWinner
+  if (lane == 0) {
+    double r = 0.0;
+    r += (double)(cur_tc - prev[pl]) * 1.0;                                       // :540-542
+    r += (double)(cur_ac - prev[MAXP + pl]) * 0.01;                               // :544-546
+    for (int q = 0; q < P; ++q)                                                   // :548-555
+      if (q != pl && prev[2 * MAXP + q] != 0 && !((alive >> q) & 1u)) r += 50.0;
+    if (over) r = (winner == pl) ? 100.0 : -100.0;                                // :520-524
+    if (flow) {
+      // :226-241 a refused action costs -0.1 and changes nothing; :243-259 terminated = game over, truncated = turn limit
+      const bool term = over && pl_ok && !rs, trunc = turns >= (int64_t)max_turns && pl_ok && !rs;
+      if (O.reward) O.reward[env] = rs ? 0.0 : (pl_ok ? r : -0.1);
+      if (O.winner) O.winner[env] = (int8_t)(term ? winner : -1);
+      O.turn_io[env] = turns;
+      if (O.turn_out) O.turn_out[env] = turns;
+      if (O.terminated) O.terminated[env] = (uint8_t)(term ? 1 : 0);
+      if (O.truncated) O.truncated[env] = (uint8_t)(trunc ? 1 : 0);
+      if (O.needs_reset) O.needs_reset[env] = (uint8_t)((term || trunc) ? 1 : 0);
+    } else {
+      if (O.reward) O.reward[env] = r;
+      if (O.winner) O.winner[env] = (int8_t)winner;
+    }
+    if (O.done) O.done[env] = (uint8_t)(over ? 1 : 0);
+  }
+  if (lane < MAXP) {
+    prev[lane] = (int32_t)tcl;
+    prev[MAXP + lane] = (int32_t)acl;
+    prev[2 * MAXP + lane] = (int32_t)((alive >> lane) & 1u);
+  }
+}
+
 template <int MAXP, int NSLOT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymArgs A) {
   using B = Board<MAXP, NSLOT>;
@@ -669,12 +773,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
   // neighbour on the board whose shown type is not MOUNTAIN; index tile*5 + {up, right, down, left}, +4 = half move
   const uint32_t src = own_p & seen & b.gt1;
   const uint32_t m0 = src & b.ok[0], m1 = src & b.ok[1], m2 = src & b.ok[2], m3 = src & b.ok[3], many = m0 | m1 | m2 | m3;
-  float* obs = A.obs + (size_t)env * 9 * (size_t)A.stride;
-  uint8_t* mask = A.mask + (size_t)env * 5 * (size_t)A.stride;
-  // the mask is five bytes per tile: laid out in LDS first and stored as whole 16-byte (or 4-byte) pieces of consecutive
-  // lanes - five byte stores per lane and slot, each lane 5 bytes from its neighbour, held this kernel at 1.4 TB/s
   __shared__ uint32_t mask_stage[WAVES_PER_BLOCK][(NSLOT * 64 * 5 + 15) / 16 * 4];
-  uint8_t* ms = reinterpret_cast<uint8_t*>(mask_stage[wave]);
   // GeneralsEnv.step's bookkeeping around the observation (generals_env.py:226-259), when asked for: a re-dealt env
   // restarts its turn count, a refused action leaves it alone
   const bool flow = A.played != nullptr;
@@ -683,97 +782,157 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
   // channel 7: min(turn_count / max_turns, 1.0) in float64, stored as float32 (:338-339)
   double tcn = (double)turns / (double)A.max_turns;
   tcn = tcn < 1.0 ? tcn : 1.0;
-  const float tc = (float)tcn;
+  gym_emit<NSLOT>(b, seen, own_p, own_any, m0, m1, m2, m3, many, (float)tcn, A.obs + (size_t)env * 9 * (size_t)A.stride,
+                  A.mask + (size_t)env * 5 * (size_t)A.stride, reinterpret_cast<uint8_t*>(mask_stage[wave]), A.stride);
+  int32_t cur_tc = 0, cur_ac = 0;
+  uint32_t tcl = 0u;
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    const int t = 64 * s + lane;
-    const bool vis = b.gather(seen, s) != 0u, mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u;
-    const bool g = b.gather(b.gen, s) != 0u, c = b.gather(b.city, s) != 0u, mt = b.gather(b.mtn, s) != 0u;
-    const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
-    const int32_t army = vis ? b.army[s] : 0;                                    // hidden and fogged tiles: army 0
-    // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
-    const float la = (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
-    if (t < A.stride) {
-      const bool in = t < b.N;
-      const size_t n = (size_t)A.stride;
-      st_stream<GVEC_NT_MASK>(obs + 0 * n + t, (in && vis) ? 1.0f : 0.0f);                                // :312-314
-      st_stream<GVEC_NT_MASK>(obs + 1 * n + t, (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f));   // :316-322 (owner -1 unless visible)
-      st_stream<GVEC_NT_MASK>(obs + 2 * n + t, in ? la : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 3 * n + t, (in && !g && !c && !mt) ? 1.0f : 0.0f);                    // :328-336 one-hot type
-      st_stream<GVEC_NT_MASK>(obs + 4 * n + t, (in && mt) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 5 * n + t, (in && c) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 6 * n + t, (in && g) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 7 * n + t, tc);                                                       // the whole plane, like obs[7, :, :] = ...
-      st_stream<GVEC_NT_MASK>(obs + 8 * n + t, 0.0f);                                                     // left zero by the reference (:341-343)
-      uint8_t* mk = ms + t * 5;
-      mk[0] = (uint8_t)k0;
-      mk[1] = (uint8_t)k1;
-      mk[2] = (uint8_t)k2;
-      mk[3] = (uint8_t)k3;
-      mk[4] = (uint8_t)k4;
-    }
-  }
-  wave_lds_fence();
-  {
-    const int nbytes = 5 * A.stride;
-    if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(A.mask) & 15u) == 0u) {  // every env's mask starts on a 16-byte boundary
-      const u32x4* s4 = reinterpret_cast<const u32x4*>(ms);
-      u32x4* g4 = reinterpret_cast<u32x4*>(mask);
-      for (int i = lane; i < (nbytes >> 4); i += 64) st_stream<GVEC_NT_MASK>(g4 + i, s4[i]);
-    } else if ((nbytes & 3) == 0 && (reinterpret_cast<uintptr_t>(A.mask) & 3u) == 0u) {
-      const uint32_t* s1 = reinterpret_cast<const uint32_t*>(ms);
-      uint32_t* g1 = reinterpret_cast<uint32_t*>(mask);
-      for (int i = lane; i < (nbytes >> 2); i += 64) st_stream<GVEC_NT_MASK>(g1 + i, s1[i]);
-    } else {
-      for (int i = lane; i < nbytes; i += 64) mask[i] = ms[i];
-    }
-  }
-  // _calculate_reward (:499-561) against the stats this kernel stored at its previous call, then store the new ones
-  const int na = __builtin_popcount(b.alive);
-  const bool over = (b.hflags & HF_DONE) != 0u;
-  const int winner = (over && b.P > 1 && na == 1) ? (31 - __builtin_clz(b.alive)) : -1;   // Engine.GetWinner
-  int32_t* prev = A.prev_stats + (size_t)env * 3 * MAXP;
-  if (lane == 0) {
-    double r = 0.0;
-    const int pl = A.player;
-    int32_t cur_tc = 0, cur_ac = 0;
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-      cur_tc = (p == pl) ? (int32_t)lst_cnt[p] : cur_tc;
-      cur_ac = (p == pl) ? (int32_t)b.hdr_get(H_ARMYCNT + p) : cur_ac;
-    }
-    r += (double)(cur_tc - prev[pl]) * 1.0;                                       // :540-542
-    r += (double)(cur_ac - prev[MAXP + pl]) * 0.01;                               // :544-546
-    for (int q = 0; q < b.P; ++q)                                                 // :548-555
-      if (q != pl && prev[2 * MAXP + q] != 0 && !((b.alive >> q) & 1u)) r += 50.0;
-    if (over) r = (winner == pl) ? 100.0 : -100.0;                                // :520-524
-    if (flow) {
-      // :226-241 a refused action costs -0.1 and changes nothing; :243-259 terminated = game over, truncated = turn limit
-      const bool term = over && pl_ok && !rs, trunc = turns >= (int64_t)A.max_turns && pl_ok && !rs;
-      if (A.reward) A.reward[env] = rs ? 0.0 : (pl_ok ? r : -0.1);
-      if (A.winner) A.winner[env] = (int8_t)(term ? winner : -1);
-      A.turn_io[env] = turns;
-      if (A.turn_out) A.turn_out[env] = turns;
-      if (A.terminated) A.terminated[env] = (uint8_t)(term ? 1 : 0);
-      if (A.truncated) A.truncated[env] = (uint8_t)(trunc ? 1 : 0);
-      if (A.needs_reset) A.needs_reset[env] = (uint8_t)((term || trunc) ? 1 : 0);
-    } else {
-      if (A.reward) A.reward[env] = r;
-      if (A.winner) A.winner[env] = (int8_t)winner;
-    }
-    if (A.done) A.done[env] = (uint8_t)(over ? 1 : 0);
+  for (int p = 0; p < MAXP; ++p) {
+    cur_tc = (p == A.player) ? (int32_t)lst_cnt[p] : cur_tc;
+    tcl = (lane == p) ? lst_cnt[p] : tcl;
   }
   // lanes H_ARMYCNT + p of the header register hold ArmyCount[p]: fetched by every lane (a cross-lane read must
   // not sit under a divergent branch: masked-off source lanes read as 0)
-  const uint32_t ac = bperm((H_ARMYCNT + (lane & (MAXP - 1))) << 2, b.hv);
-  if (lane < MAXP) {
-    uint32_t tcl = 0u;
+  const uint32_t acl = bperm((H_ARMYCNT + (lane & (MAXP - 1))) << 2, b.hv);
+  cur_ac = (int32_t)rdlane(acl, A.player);
+  const GymFlowOut O{A.reward, A.done, A.winner, A.turn_io, A.turn_out, A.terminated, A.truncated, A.needs_reset};
+  gym_bookkeeping<MAXP>(env, A.player, b.P, b.alive, (b.hflags & HF_DONE) != 0u, cur_tc, cur_ac, tcl, acl,
+                        A.prev_stats + (size_t)env * 3 * MAXP, flow, rs, pl_ok, turns, A.max_turns, O);
+}
+
+// GeneralsEnv.step for every env in ONE launch (gvec_gym_step) = gvec_agent_actions + gvec_gym_actions + gvec_step +
+// gvec_gym_finish_step, which it equals bit for bit (tests/test_vector_env.py): the learner's Discrete(N*5) action is
+// decoded against the valid-action mask of the resident state (recomputed from the planes in registers - the bytes
+// gym_observe wrote are not read back), the opponents' moves come from the on-device agent, the turn is played, and the
+// observation / mask / reward / flags of the NEW state leave while the board is still in registers.
+template <int MAXP, int NSLOT, bool ODD>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_step_kernel(StepArgs A, GymStepArgs G) {
+  constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
+  constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
+  constexpr int STAGE_DW = (NSLOT * 64 * 5 + 15) / 16 * 4;  // the gym mask's stage (5 bytes a tile) is the larger user of the army shadow
+  static_assert(STAGE_DW >= NSLOT * 64, "the stage also serves as the action phase's army shadow");
+  using B = Turn<MAXP, NSLOT>;
+  constexpr int PPR = B::PPR, ROWL = B::ROWL, NR = B::NR;
+  __shared__ int32_t army_shadow[WAVES_PER_BLOCK][STAGE_DW];
+  __shared__ uint32_t act_scratch[WAVES_PER_BLOCK][B::ACT_SCRATCH_DW];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  B b;
+  b.larmy = army_shadow[wave];
+  b.lscr = act_scratch[wave];
+  const ArmyRef army_env = army_ref<NSLOT>(A.army16, A.army32, env);
+  load_turn<true>(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * ROW_DW, army_env, FD, A.zeros);
+  b.small = !(b.hflags & HF_WIDE);
+  const int pl = G.player;
+  // the learner's planes, replicated into every row: row pl % PPR of register pl / PPR
+  auto learner = [&](const uint32_t (&reg)[NR]) {
+    uint32_t out = 0u;
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) tcl = (lane == p) ? lst_cnt[p] : tcl;
-    prev[lane] = (int32_t)tcl;
-    prev[MAXP + lane] = (int32_t)ac;
-    prev[2 * MAXP + lane] = (int32_t)((b.alive >> lane) & 1u);
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t g = bperm((((pl % PPR) * ROWL) + B::col()) << 2, reg[k]);
+      out = (pl / PPR == k) ? g : out;
+    }
+    return out;
+  };
+  // ---- GeneralsEnv.step's action handling (generals_env.py:226-259, :389-441; gym_actions_kernel) -------------
+  const long long a = (long long)uni64((uint64_t)G.gym_actions[env]);
+  const bool rs = uni((int)G.resetting[env]) != 0;
+  bool valid, accepted, half;
+  int from, d;
+  {
+    const uint32_t seen = (b.hflags & HF_FOG) ? learner(b.vis) : b.valid;
+    const uint32_t src = learner(b.own) & seen & b.gt1;
+    const long long n5 = 5ll * G.stride;
+    const bool in_range = a >= 0 && a < n5;
+    from = in_range ? (int)(a / 5) : 0;
+    const int info = in_range ? (int)(a % 5) : 0;
+    const int fy = (int)(__umul24((uint32_t)from, (uint32_t)b.recipW) >> 16), fx = from - (int)__umul24((uint32_t)fy, (uint32_t)b.W);  // from < 1024
+    half = info == 4;
+    d = half ? 3 : info;
+    if (half) {  // the FIRST of up / right / down / left whose target is on the board (mountains are not checked there)
+      if (fx - 1 >= 0) d = 3;
+      if (fy + 1 < b.H) d = 2;
+      if (fx + 1 < b.W) d = 1;
+      if (fy - 1 >= 0) d = 0;
+    }
+    // a tile index beyond the env's own board has no mask bit: the planes are zero there
+    const uint32_t wsrc = rdlane(src, from >> 5);
+    const uint32_t o0 = rdlane(b.ok[0], from >> 5), o1 = rdlane(b.ok[1], from >> 5), o2 = rdlane(b.ok[2], from >> 5), o3 = rdlane(b.ok[3], from >> 5);
+    const uint32_t bit = 1u << (from & 31);
+    const bool s_ok = (wsrc & bit) != 0u;
+    const bool k0 = s_ok && (o0 & bit), k1 = s_ok && (o1 & bit), k2 = s_ok && (o2 & bit), k3 = s_ok && (o3 & bit);
+    const bool kinfo = (info == 0) ? k0 : (info == 1) ? k1 : (info == 2) ? k2 : (info == 3) ? k3 : (k0 || k1 || k2 || k3);
+    valid = in_range && kinfo;
+    const bool kd = (d == 0) ? k0 : (d == 1) ? k1 : (d == 2) ? k2 : k3;
+    accepted = valid && kd;   // the server validates the move it received (action_validator.go:114-139)
   }
+  const bool played = accepted || rs;
+  if (lane == 0) {
+    if (G.played) G.played[env] = (uint8_t)played;
+    if (G.invalid) G.invalid[env] = (uint8_t)(!valid && !rs);
+    if (G.error) G.error[env] = (uint8_t)(valid && !accepted && !rs);
+  }
+  // ---- the turn (step_kernel's body; an env whose action was refused sits the call out) --------------------------
+  if (played) {
+    uint32_t err = 0u;
+    bool types_dirty = false;
+    if ((b.hflags & HF_DONE) || rs) {
+      redeal<MAXP, NSLOT>(b, A, env, FD, ROW_DW);
+      types_dirty = true;
+    } else {
+      uint32_t m[NR][4];
+      b.template legal_planes<false>(m);
+      const uint32_t mine = agent_sample<MAXP, NSLOT>(b, m, env_key_of(A.seed_base, (uint32_t)env), A);
+      typename B::ActVec av = agent_actvec<MAXP, NSLOT>(b, mine, A.invalid_permille > 0);
+      // the learner's slot: the accepted move (on the board and legal by construction of the mask)
+      const int tt = from + ((d == 0) ? -b.W : (d == 1) ? 1 : (d == 2) ? b.W : -1);
+      av.meta = (lane == pl) ? (16u | (half ? 32u : 0u)) : av.meta;
+      av.ft = (lane == pl) ? from : av.ft;
+      av.tt = (lane == pl) ? tt : av.tt;
+      bool aborted;
+      err = b.turn_step(av, A, aborted);
+      b.refresh_gt1();
+      b.hdr_set(H_CNT_STEPS, b.hdr_get(H_CNT_STEPS) + 1u);
+      if (aborted) b.hdr_set(H_CNT_ABORT, b.hdr_get(H_CNT_ABORT) + 1u);
+      if (b.hflags & HF_DONE) b.hdr_set(H_CNT_DONE, b.hdr_get(H_CNT_DONE) + 1u);
+    }
+    b.store_army_staged(army_env);
+    b.settle_lists();
+    b.store_hdr(A.hdr + (size_t)env * HDR_DW, err);
+    if (types_dirty) b.store_planes(A.rows + (size_t)env * ROW_DW, FD, ROW_DW, true);
+    else b.store_planes_staged(A.rows + (size_t)env * ROW_DW, FD);
+    if (A.err && lane == 0) A.err[env] = (int32_t)err;
+  } else if (A.err && lane == 0) {
+    A.err[env] = 0;
+  }
+  // ---- observation, mask, reward, flags of the state as it is now (gym_observe_kernel's body) ----------------------
+  const uint32_t own_p = learner(b.own);
+  const uint32_t seen = (b.hflags & HF_FOG) ? learner(b.vis) : b.valid;
+  uint32_t own_any = 0u;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) own_any |= b.own[k];
+  own_any = B::or_rows(own_any);
+  const uint32_t src = own_p & seen & b.gt1;
+  const uint32_t m0 = src & b.ok[0], m1 = src & b.ok[1], m2 = src & b.ok[2], m3 = src & b.ok[3], many = m0 | m1 | m2 | m3;
+  const int64_t turns = rs ? 0 : G.turn_io[env] + (played ? 1 : 0);
+  double tcn = (double)turns / (double)G.max_turns;
+  tcn = tcn < 1.0 ? tcn : 1.0;
+  wave_lds_fence();  // the staged state stores above have read the stage
+  gym_emit<NSLOT>(b, seen, own_p, own_any, m0, m1, m2, m3, many, (float)tcn, G.obs + (size_t)env * 9 * (size_t)G.stride,
+                  G.mask + (size_t)env * 5 * (size_t)G.stride, reinterpret_cast<uint8_t*>(army_shadow[wave]), G.stride);
+  // per-player len(OwnedTiles): row totals in the rows' last lanes, handed to lane p
+  uint32_t tcl = 0u;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const uint32_t sc = row_scan_add<ROWL>((uint32_t)__builtin_popcount(b.lst[k]));
+    const uint32_t got = bperm((((lane % PPR) * ROWL) + ROWL - 1) << 2, sc);
+    tcl = (lane / PPR == k) ? got : tcl;
+  }
+  const uint32_t acl = bperm((H_ARMYCNT + (lane & (MAXP - 1))) << 2, b.hv);
+  const GymFlowOut O{G.reward, nullptr, G.winner, G.turn_io, G.turn_out, G.terminated, G.truncated, G.needs_reset};
+  gym_bookkeeping<MAXP>(env, pl, b.P, b.alive, (b.hflags & HF_DONE) != 0u, (int32_t)rdlane(tcl, pl), (int32_t)rdlane(acl, pl), tcl, acl,
+                        G.prev_stats + (size_t)env * 3 * MAXP, true, rs, played, turns, G.max_turns, O);
 }
 
 // GeneralsEnv.step's action handling for player `player` of every env (one thread per env):
@@ -1406,6 +1565,18 @@ hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s)
   return dispatch(v, [&](auto P_, auto S_) {
     hipLaunchKernelGGL((gym_observe_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK),
                        0, s, a);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_gym_step(const Variant& v, const StepArgs& in, const GymStepArgs& g, hipStream_t s) {
+  const StepArgs a = with_seed_bases(in);
+  return dispatch(v, [&](auto P_, auto S_) {
+    constexpr int P = decltype(P_)::value, S = decltype(S_)::value;
+    const bool odd = a.fd == 2 * S - 1;
+    if ((!odd && a.fd != 2 * S) || a.row_dw != (Planes<P>::COUNT * a.fd + 3) / 4 * 4) return hipErrorInvalidValue;
+    const dim3 grid = wave_grid(a.num_envs), block(64 * WAVES_PER_BLOCK);
+    if (odd) hipLaunchKernelGGL((gym_step_kernel<P, S, true>), grid, block, 0, s, a, g);
+    else hipLaunchKernelGGL((gym_step_kernel<P, S, false>), grid, block, 0, s, a, g);
     return hipGetLastError();
   });
 }

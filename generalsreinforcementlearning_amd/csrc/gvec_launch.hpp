@@ -164,6 +164,26 @@ struct GymActArgs {
   uint8_t* error;
   int32_t num_envs, stride, pstride, player;
 };
+// gvec_gym_step: GeneralsEnv.step for every env in one launch (gym_step_kernel)
+struct GymStepArgs {
+  const int64_t* gym_actions;  // [B] indices into Discrete(board_size * 5)
+  const uint8_t* resetting;    // [B] needs_reset of the previous step
+  int64_t* turn_io;            // [B] in / out: GeneralsEnv.turn_count
+  int64_t* turn_out;           // [B] out or null
+  float* obs;                  // [B][9][stride]
+  uint8_t* mask;               // [B][stride*5]
+  double* reward;              // [B] outputs, any may be null
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int8_t* winner;
+  uint8_t* needs_reset;
+  uint8_t* played;
+  uint8_t* invalid;
+  uint8_t* error;
+  int32_t* prev_stats;         // [B][3*MAXP], as GymArgs
+  int32_t stride, player, max_turns;
+};
+hipError_t launch_gym_step(const Variant& v, const StepArgs& a, const GymStepArgs& g, hipStream_t s);
 hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s);
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s);
 hipError_t launch_snapshot(const Variant& v, const ExperienceArgs& a, hipStream_t s);

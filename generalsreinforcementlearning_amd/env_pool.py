@@ -1,0 +1,294 @@
+"""ParallelVecEnvPool + ReplayBuffer — the collection surface `train_dqn_parallel.py` consumes, over ONE vector env.
+
+Reference: python/generals_gym/vector_env.py:28-192 (ParallelEnvPool: N GeneralsEnv instances, one worker thread each,
+every worker running whole episodes and pushing (state, action, reward, next_state, done) into a shared buffer) and
+python/generals_gym/replay_buffer.py:13-55 (thread-safe ring).  Same constructor keywords, same properties
+(`total_env_steps`, `total_episodes`, `alive_workers`), same `start / stop / pop_episode_results`, same per-worker
+behaviour - the sequence of transitions worker w pushes and the (episode_reward, episode_length, worker_id) results it
+reports are those of the reference's worker w given the same env behaviour and the same `action_fn`
+(tests/test_env_pool.py replays fixtures recorded from the reference's own classes).
+
+What differs, by construction of a vector env:
+  * `env_factory(num_envs)` is called ONCE and returns the vector env (GeneralsVecEnv, numpy mode) - the reference calls
+    `env_factory(worker_id)` once per worker;
+  * one collector thread steps all "workers" (= env indices) in lock-step instead of N threads doing gRPC round trips;
+  * an episode that ends (terminated / truncated, or cut at `max_steps_per_episode` - the pool then asks the env to
+    re-deal that board with `force_reset`) starts its successor on the env's next step, which returns the new episode's
+    first observation with info["reset"] set; that step is the worker's `env.reset()` and is not a transition;
+  * `batched_actions=True`: `action_fn(states[k], valid_masks[k], worker_ids[k], rngs) -> actions[k]` for the k workers
+    that play this step (rngs: the list of all workers' RNGs, indexed by worker id) - one policy forward for all envs;
+    the default keeps the reference's per-env signature `(state, valid_mask, worker_id, rng) -> int`
+    with one private `random.Random(seed * 1000 + worker_id)` per worker (vector_env.py:138).
+"""
+import logging
+import random
+import threading
+import time
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+class ReplayBuffer:
+    """Thread-safe ring-buffer replay memory (replay_buffer.py:13-55): `push` evicts the oldest transition when full,
+    `sample` draws uniformly without replacement with the module-level `random` (same indices as the reference's
+    `random.sample(list, k)` for the same seed: the draw depends on the length only), `total_pushed` is the monotonic
+    env-step counter, `len()` the fill.  Stored as arrays (one slab per field, allocated at the first push) rather than a
+    list of tuples, so `push_batch` writes a whole vector step under one lock and `sample_arrays` hands a learner stacked
+    batches without a Python loop."""
+
+    def __init__(self, capacity):
+        if capacity <= 0:
+            raise ValueError(f"capacity must be positive, got {capacity}")   # replay_buffer.py:22-23
+        self.capacity = int(capacity)
+        self._state = self._next = self._action = self._reward = self._done = None
+        self._size = 0
+        self._write_idx = 0
+        self._total_pushed = 0
+        self._lock = threading.Lock()
+
+    def _alloc(self, state):
+        s = np.asarray(state)
+        self._state = np.empty((self.capacity,) + s.shape, s.dtype)
+        self._next = np.empty((self.capacity,) + s.shape, s.dtype)
+        self._action = np.empty(self.capacity, np.int64)
+        self._reward = np.empty(self.capacity, np.float64)
+        self._done = np.empty(self.capacity, bool)
+
+    def push(self, state, action, reward, next_state, done):
+        with self._lock:
+            if self._state is None:
+                self._alloc(state)
+            i = self._write_idx
+            self._state[i], self._next[i] = state, next_state
+            self._action[i], self._reward[i], self._done[i] = action, reward, done
+            self._write_idx = (i + 1) % self.capacity                       # :36
+            self._size = min(self._size + 1, self.capacity)
+            self._total_pushed += 1
+
+    def push_batch(self, states, actions, rewards, next_states, dones):
+        """k transitions in order (equivalent to k `push` calls) under one lock."""
+        k = len(actions)
+        if k == 0:
+            return
+        with self._lock:
+            if self._state is None:
+                self._alloc(states[0])
+            idx = (self._write_idx + np.arange(k)) % self.capacity
+            if k > self.capacity:                                            # only the last `capacity` survive, as with k pushes
+                keep = slice(k - self.capacity, k)
+                idx, states, actions, rewards, next_states, dones = idx[keep], states[keep], actions[keep], rewards[keep], next_states[keep], dones[keep]
+            self._state[idx], self._next[idx] = states, next_states
+            self._action[idx], self._reward[idx], self._done[idx] = actions, rewards, dones
+            self._write_idx = (self._write_idx + k) % self.capacity
+            self._size = min(self._size + k, self.capacity)
+            self._total_pushed += k
+
+    def _item(self, i):
+        return (self._state[i], int(self._action[i]), float(self._reward[i]), self._next[i], bool(self._done[i]))
+
+    def sample(self, batch_size):
+        """List of (state, action, reward, next_state, done) tuples, like the reference (:40-43); ValueError when the
+        buffer holds fewer than batch_size transitions (random.sample's own)."""
+        with self._lock:
+            return [self._item(i) for i in random.sample(range(self._size), batch_size)]
+
+    def sample_arrays(self, batch_size):
+        """The same draw as stacked arrays: (states, actions, rewards, next_states, dones)."""
+        with self._lock:
+            idx = np.asarray(random.sample(range(self._size), batch_size), np.int64)
+            return self._state[idx], self._action[idx], self._reward[idx], self._next[idx], self._done[idx]
+
+    @property
+    def total_pushed(self):
+        with self._lock:
+            return self._total_pushed
+
+    def __len__(self):
+        with self._lock:
+            return self._size
+
+
+class ParallelVecEnvPool:
+    """vector_env.py:28-192 over a vector env; see the module docstring for what is kept and what differs."""
+
+    def __init__(self, num_envs, env_factory, action_fn, replay_buffer, max_steps_per_episode=200, max_env_retries=3, seed=42,
+                 batched_actions=False, retry_sleep_s=2.0):
+        self.num_envs = num_envs
+        self.env_factory = env_factory
+        self.action_fn = action_fn
+        self.replay_buffer = replay_buffer
+        self.max_steps_per_episode = max_steps_per_episode
+        self.max_env_retries = max_env_retries
+        self.seed = seed
+        self.batched_actions = bool(batched_actions)
+        self.retry_sleep_s = retry_sleep_s
+
+        self._stop_event = threading.Event()
+        self._threads = []
+        self._stats_lock = threading.Lock()
+        self._total_episodes = 0
+        self._alive_workers = 0
+        self._episode_results = []     # (episode_reward, episode_length, worker_id), drained by the trainer
+        # private RNG per worker (vector_env.py:136-138): shared module-level RNGs would correlate exploration between workers
+        self._rngs = [random.Random(self.seed * 1000 + w) for w in range(num_envs)]
+        self._env = None
+        self._state = self._mask = None
+        self._ep_reward = np.zeros(num_envs, np.float64)
+        self._ep_length = np.zeros(num_envs, np.int64)
+        self._starting = np.zeros(num_envs, bool)   # the worker's next vector step is its env.reset()
+
+    # ---- the reference's public surface (vector_env.py:62-112) ----------------------------------------------
+    def start(self):
+        """One daemon collector thread for all environments."""
+        if self._threads:
+            raise RuntimeError("Pool already started")
+        self._stop_event.clear()
+        with self._stats_lock:
+            self._alive_workers = self.num_envs
+        t = threading.Thread(target=self._worker_loop, name="env-worker-vec", daemon=True)
+        self._threads.append(t)
+        t.start()
+        logger.info("Started the collector for %d envs", self.num_envs)
+
+    def stop(self, join_timeout=10.0):
+        self._stop_event.set()
+        for t in self._threads:
+            t.join(timeout=join_timeout)
+            if t.is_alive():
+                logger.warning("Worker %s did not stop within %.1fs", t.name, join_timeout)
+        self._threads = []
+
+    @property
+    def total_env_steps(self):
+        return self.replay_buffer.total_pushed
+
+    @property
+    def total_episodes(self):
+        with self._stats_lock:
+            return self._total_episodes
+
+    @property
+    def alive_workers(self):
+        with self._stats_lock:
+            return self._alive_workers
+
+    def pop_episode_results(self):
+        with self._stats_lock:
+            results = self._episode_results
+            self._episode_results = []
+            return results
+
+    # ---- collection ---------------------------------------------------------------------------------------------
+    def _create_env(self, old_env=None):
+        """(Re)create the vector env with retries (vector_env.py:114-134)."""
+        for attempt in range(self.max_env_retries):
+            try:
+                if old_env is not None:
+                    try:
+                        old_env.close()
+                    except Exception:
+                        pass
+                    old_env = None
+                env = self.env_factory(self.num_envs)
+                logger.info("vector environment (re)created")
+                return env
+            except Exception as e:
+                logger.warning("env creation attempt %d/%d failed: %s", attempt + 1, self.max_env_retries, e)
+                if attempt < self.max_env_retries - 1:
+                    time.sleep(self.retry_sleep_s)
+        raise RuntimeError("failed to create the vector environment")
+
+    def _begin(self):
+        """Every worker's first `env.reset()` (vector_env.py:166-167)."""
+        self._state, info = self._env.reset()
+        self._mask = info.get("valid_actions_mask")
+        if self._mask is None:
+            self._mask = np.ones((self.num_envs, self._env.single_action_n), bool)
+        self._ep_reward[:] = 0.0
+        self._ep_length[:] = 0
+        self._starting[:] = False
+
+    def _actions(self):
+        """The policy is asked only for the workers that will play: a worker whose next step is its `env.reset()` chooses
+        nothing (and draws nothing from its RNG), as in the reference's loop."""
+        acts = np.zeros(self.num_envs, np.int64)
+        idx = np.flatnonzero(~self._starting)
+        if len(idx) == 0:
+            return acts
+        if self.batched_actions:
+            acts[idx] = np.asarray(self.action_fn(self._state[idx], self._mask[idx], idx, self._rngs), np.int64).reshape(len(idx))
+        else:
+            for w in idx:
+                acts[w] = self.action_fn(self._state[w], self._mask[w], int(w), self._rngs[w])
+        return acts
+
+    def _collect_step(self):
+        """One vector step = one iteration of every worker's `_run_episode` loop (vector_env.py:172-192)."""
+        state = self._state
+        actions = self._actions()
+        next_state, reward, terminated, truncated, info = self._env.step(actions)
+        reward = np.asarray(reward, np.float64)
+        done = np.asarray(terminated, bool) | np.asarray(truncated, bool)
+        fresh = np.asarray(info.get("reset", np.zeros(self.num_envs, bool)), bool)   # this step was the worker's env.reset()
+        live = ~fresh
+        idx = np.flatnonzero(live)
+        if len(idx):
+            if hasattr(self.replay_buffer, "push_batch"):
+                self.replay_buffer.push_batch(np.array(state[idx]), actions[idx], reward[idx], np.array(next_state[idx]), done[idx])
+            else:
+                for w in idx:
+                    self.replay_buffer.push(np.array(state[w]), int(actions[w]), float(reward[w]), np.array(next_state[w]), bool(done[w]))
+        self._ep_reward[live] += reward[live]
+        self._ep_length[live] += 1
+        over = live & (done | (self._ep_length >= self.max_steps_per_episode))
+        if over.any():
+            with self._stats_lock:
+                for w in np.flatnonzero(over):
+                    self._total_episodes += 1
+                    self._episode_results.append((float(self._ep_reward[w]), int(self._ep_length[w]), int(w)))
+            cut = over & ~done
+            if cut.any():
+                self._env.force_reset(cut)      # the reference's next `env.reset()`: the env's own flags do not say so
+            self._ep_reward[over] = 0.0
+            self._ep_length[over] = 0
+        self._starting = over
+        self._state = next_state
+        m = info.get("valid_actions_mask")
+        self._mask = m if m is not None else np.ones((self.num_envs, self._env.single_action_n), bool)
+
+    def collect(self, steps):
+        """Synchronous form for trainers and tests that own the loop: `steps` vector steps in the caller's thread."""
+        if self._env is None:
+            self._env = self._create_env()
+            self._begin()
+        for _ in range(steps):
+            self._collect_step()
+
+    def _worker_loop(self):
+        try:
+            if self._env is None:
+                self._env = self._create_env()
+                self._begin()
+            while not self._stop_event.is_set():
+                try:
+                    self._collect_step()
+                except Exception as e:
+                    if self._stop_event.is_set():
+                        break
+                    logger.warning("vector step failed: %s", e)      # running episodes are lost, like a failed worker episode
+                    self._env = self._create_env(old_env=self._env)
+                    self._begin()
+        except Exception as e:
+            logger.error("collector dying: %s", e)
+        finally:
+            if self._env is not None:
+                try:
+                    self._env.close()
+                except Exception:
+                    pass
+                self._env = None
+            with self._stats_lock:
+                self._alive_workers = 0
+            logger.info("collector exited")

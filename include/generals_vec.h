@@ -344,6 +344,20 @@ int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_acti
                          const uint8_t* resetting, gvec_action* actions, uint8_t* played, uint8_t* invalid,
                          uint8_t* error);
 
+/* GeneralsEnv.step (generals_env.py:226-259) for every env in ONE launch: exactly
+ *   gvec_agent_actions(agent_seed, 0) -> gvec_gym_actions(gym_actions, the last observation's mask, resetting) ->
+ *   gvec_step(device actions, no err / legal output) -> gvec_gym_finish_step(resetting, played, ...)
+ * with the same outputs bit for bit, without the intermediate buffers: the learner's action is decoded against the
+ * valid-action mask of the resident state (recomputed on the fly), the other players move like the on-device agent, the
+ * turn is played and observation / mask / reward / flags of the new state are written while the board is in registers.
+ * `resetting` = the needs_reset output of the previous call (zeros after a reset).  Needs auto_reset and a board pool
+ * (GVEC_E_INVALID otherwise: a re-deal is how an episode ends here).  obs / mask / turn_count / gym_actions / resetting
+ * are required, every other output may be NULL.  Device pointers only; enqueued on the handle's stream. */
+int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const int64_t* gym_actions, const uint8_t* resetting,
+                      int64_t* turn_count, int32_t max_turns, float* obs, uint8_t* mask, double* reward, uint8_t* terminated,
+                      uint8_t* truncated, int8_t* winner, uint8_t* needs_reset, int64_t* turn_out, uint8_t* played,
+                      uint8_t* invalid, uint8_t* error);
+
 /* ---- experience gather support ---------------------------------------
  * Writes the compact state records of envs [env_begin, env_begin+n) into a device
  * buffer (e.g. a torch tensor handed to RCCL) as a slab [n] headers | [n] plane blocks |

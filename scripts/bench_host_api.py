@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a Python consumer sees: host-buffer API latencies (read_state / step), and the gym-style vector env in its
-two modes - host numpy (state read-back over PCIe + numpy observation building) and device_outputs (gym kernels,
-CUDA tensors, actions decoded on the device).   usage: scripts/bench_host_api.py [B]"""
+two modes - numpy in / out (the gym kernel's outputs copied to pinned host buffers) and device_outputs (CUDA tensors,
+actions decoded on the device, one launch per step).   usage: scripts/bench_host_api.py [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,8 +21,7 @@ print(f"B={B}: game_state() {t(lambda: e.game_state()):.2f} ms | step(host acts)
       f"step+mask {t(lambda: e.step(acts, want_mask=True)):.2f} ms | legal_action_mask_bits {t(lambda: e.legal_action_mask_bits()):.2f} ms", flush=True)
 del e
 
-for label, kw in (("numpy_reference (state read-back + numpy rebuild)", dict(numpy_reference=True)),
-                  ("default: numpy in / out over the gym kernels", dict())):
+for label, kw in (("default: numpy in / out over the gym kernels", dict()),):
     env = GeneralsVecEnv(num_envs=B, board_width=20, board_height=20, max_players=4, **kw)
     obs, info = env.reset(seed=3)
     holder = [info]
@@ -48,6 +47,12 @@ for BB in sorted({B, 65536}):
         for _ in range(n): dstep()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    ms = timed(20)
-    print(f"GeneralsVecEnv.step (device_outputs, B={BB}) {ms:8.3f} ms  ({BB / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
+    ms = timed(50)
+    print(f"GeneralsVecEnv.step (device_outputs, B={BB}, argmax policy on the device) {ms:8.4f} ms  ({BB / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
+    fixed = torch.argmax(holder[0]["valid_actions_mask"].to(torch.uint8), dim=1)
+    def fstep():
+        env.step(fixed)
+    dstep = fstep
+    ms = timed(200)
+    print(f"GeneralsVecEnv.step (device_outputs, B={BB}, the step alone: one gvec_gym_step launch) {ms:8.4f} ms  ({BB / ms * 1e3 / 1e6:.3f} M env-steps/s)", flush=True)
     env.close()

@@ -1,0 +1,261 @@
+"""ParallelVecEnvPool / ReplayBuffer against what the REFERENCE's own ParallelEnvPool / ReplayBuffer did
+with the same scripted environment (tests/golden/pool_fixtures.json, recorded by tests/golden/make_pool_fixtures.py from
+python/generals_gym/vector_env.py + replay_buffer.py), then - under -m gpu - over the real GeneralsVecEnv."""
+import json
+import os
+import random
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import _scripted_env as S
+from generalsreinforcementlearning_amd.env_pool import ParallelVecEnvPool, ReplayBuffer
+
+FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pool_fixtures.json")))
+
+
+def _ids(o):
+    return [int(o[0, 0, 0]), int(o[0, 0, 1]), int(o[0, 1, 0]), int(o[0, 1, 1])]
+
+
+@pytest.mark.parametrize("batched", [False, True], ids=["per_env_action_fn", "batched_action_fn"])
+def test_pool_pushes_what_the_reference_pool_pushes(batched):
+    """Per worker: the same transitions in the same order, the same (episode_reward, episode_length, worker_id) results -
+    max_steps_per_episode cuts, the env's own terminations and truncations, the private per-worker RNG streams."""
+    f = FIX["pool"]
+    W, E = f["num_envs"], f["episodes_per_worker"]
+
+    class Buf:                                   # a reference-shaped buffer: push() only
+        def __init__(self):
+            self.items, self.total_pushed = [], 0
+
+        def push(self, s, a, r, ns, d):
+            self.items.append((s, a, r, ns, d))
+            self.total_pushed += 1
+
+    def batched_fn(states, masks, workers, rngs):
+        return np.array([S.random_action_fn(states[i], masks[i], w, rngs[w]) for i, w in enumerate(workers)])
+
+    buf = Buf()
+    pool = ParallelVecEnvPool(num_envs=W, env_factory=S.ScriptedVecEnv, action_fn=batched_fn if batched else S.random_action_fn,
+                              replay_buffer=buf, max_steps_per_episode=f["max_steps_per_episode"], seed=f["seed"], batched_actions=batched)
+    done_eps = {w: 0 for w in range(W)}
+    results = {w: [] for w in range(W)}
+    while min(done_eps.values()) < E:
+        pool.collect(1)
+        for rew, length, w in pool.pop_episode_results():
+            results[w].append([rew, length, w])
+            done_eps[w] += 1
+    assert pool.total_env_steps == buf.total_pushed
+    per = {w: [] for w in range(W)}
+    for s, a, r, ns, d in buf.items:
+        assert isinstance(a, int) and isinstance(d, bool) and isinstance(r, float)
+        per[int(s[0, 0, 0])].append({"state": _ids(s), "action": a, "reward": r, "next_state": _ids(ns), "done": d})
+    for w in range(W):
+        want = f["transitions"][str(w)]
+        got = [t for t in per[w] if t["state"][1] < E]            # the reference stopped every worker after E episodes
+        assert got == want, (w, next((i, g, x) for i, (g, x) in enumerate(zip(got, want)) if g != x) if len(got) == len(want) else (len(got), len(want)))
+        assert results[w][:E] == f["episode_results"][str(w)]
+
+
+def test_replay_buffer_matches_the_reference_buffer():
+    f = FIX["buffer"]
+    rb = ReplayBuffer(f["capacity"])
+    for i in range(f["pushes"]):
+        rb.push(S.obs_of(0, 0, i, -1), i, i * 0.5, S.obs_of(0, 0, i + 1, i), i % 4 == 3)
+    assert rb.total_pushed == f["total_pushed"] and len(rb) == f["len"]
+    random.seed(f["seed"])
+    draws = [[[_ids(s), a, r, _ids(ns), d] for s, a, r, ns, d in rb.sample(3)] for _ in range(2)]
+    assert draws == f["draws"]
+    random.seed(f["seed"])
+    st, ac, rw, nx, dn = rb.sample_arrays(3)                     # the same draw as arrays
+    assert [[_ids(st[i]), int(ac[i]), float(rw[i]), _ids(nx[i]), bool(dn[i])] for i in range(3)] == f["draws"][0]
+    with pytest.raises(ValueError):
+        rb.sample(6)
+    with pytest.raises(ValueError):
+        ReplayBuffer(0)
+    assert f["sample_more_than_len"] == "ValueError" and f["capacity_zero"] == "ValueError"
+
+
+def test_push_batch_equals_pushes():
+    a, b = ReplayBuffer(7), ReplayBuffer(7)
+    rng = np.random.default_rng(0)
+    n = 0
+    for k in (3, 5, 1, 9, 2):
+        s, ns = rng.random((k, 9, 2, 2), np.float32), rng.random((k, 9, 2, 2), np.float32)
+        ac, rw, dn = rng.integers(0, 50, k), rng.random(k), rng.random(k) < 0.3
+        a.push_batch(s, ac, rw, ns, dn)
+        for i in range(k):
+            b.push(s[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+        n += k
+        assert a.total_pushed == b.total_pushed == n and len(a) == len(b)
+        random.seed(1)
+        x = a.sample(len(a))
+        random.seed(1)
+        y = b.sample(len(b))
+        for (s1, a1, r1, n1, d1), (s2, a2, r2, n2, d2) in zip(x, y):
+            assert np.array_equal(s1, s2) and a1 == a2 and r1 == r2 and np.array_equal(n1, n2) and d1 == d2
+
+
+def test_replay_buffer_thread_safety():
+    """python/test_parallel_env.py:19-51, against this buffer."""
+    capacity, per_thread, n_threads = 500, 1000, 4
+    buf = ReplayBuffer(capacity)
+    errors = []
+
+    def pusher(tid):
+        try:
+            for i in range(per_thread):
+                buf.push(np.zeros((9, 5, 5), np.float32), i, 0.5, np.zeros((9, 5, 5), np.float32), False)
+                if len(buf) >= 32:
+                    assert len(buf.sample(32)) == 32
+        except Exception as e:
+            errors.append((tid, e))
+
+    ts = [threading.Thread(target=pusher, args=(t,)) for t in range(n_threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors and buf.total_pushed == n_threads * per_thread and len(buf) == capacity
+
+
+def test_pool_thread_start_stop_and_env_recreation():
+    """start / stop / alive_workers (vector_env.py:62-112) and the retry pattern (:114-134, :141-150): a step that raises
+    makes the pool recreate its env; a factory that keeps failing kills the collector after max_env_retries."""
+    made = {"n": 0}
+
+    class Flaky(S.ScriptedVecEnv):
+        def step(self, actions):
+            if made["n"] == 1 and self.t.max() >= 2:
+                raise RuntimeError("lost connection")
+            return super().step(actions)
+
+    def factory(n):
+        made["n"] += 1
+        if made["n"] >= 3:
+            raise RuntimeError("server gone")
+        return Flaky(n)
+
+    buf = ReplayBuffer(1000)
+    pool = ParallelVecEnvPool(4, factory, S.random_action_fn, buf, max_steps_per_episode=5, max_env_retries=2, retry_sleep_s=0.01)
+    pool.start()
+    with pytest.raises(RuntimeError):
+        pool.start()
+    assert pool.alive_workers == 4
+    t0 = time.time()
+    while pool.total_episodes < 8 and time.time() - t0 < 20:
+        time.sleep(0.01)
+    assert made["n"] == 2 and pool.total_episodes >= 8          # env 1 failed once, env 2 took over
+    made["n"] = 2
+
+    class Dead(S.ScriptedVecEnv):
+        def step(self, actions):
+            raise RuntimeError("down")
+    pool._env.__class__ = Dead                                   # the next step fails and the factory refuses: the collector dies
+    t0 = time.time()
+    while pool.alive_workers and time.time() - t0 < 20:
+        time.sleep(0.01)
+    assert pool.alive_workers == 0
+    pool.stop(join_timeout=5.0)
+    assert pool.total_env_steps == buf.total_pushed > 0
+
+
+# ---- over the real vector env ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_pool_over_generals_vec_env_pushes_the_env_s_own_transitions():
+    """A random `action_fn` drives ParallelVecEnvPool over GeneralsVecEnv; a twin env stepped by hand with the same actions
+    says what every transition must be: state / next_state are the observations GeneralsVecEnv.step returned, reward and
+    done its outputs, the step after an episode's end (re-deal) is not a transition, and an episode cut at
+    max_steps_per_episode restarts on a fresh board."""
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    B, MAXS = 24, 12
+    kw = dict(board_width=8, board_height=8, max_players=2, max_turns=30, seed=6, board_pool=32)
+    log = []
+
+    def action_fn(state, valid_mask, worker_id, rng):
+        v = np.flatnonzero(valid_mask)
+        a = int(rng.choice(list(v))) if len(v) and rng.random() > 0.1 else int(rng.randrange(len(valid_mask)))   # 10 %: maybe invalid
+        log.append((worker_id, a))
+        return a
+
+    class Buf:
+        def __init__(self):
+            self.items, self.total_pushed = [], 0
+
+        def push(self, s, a, r, ns, d):
+            self.items.append((s, a, r, ns, d))
+            self.total_pushed += 1
+
+    buf = Buf()
+    pool = ParallelVecEnvPool(B, lambda n: GeneralsVecEnv(n, **kw), action_fn, buf, max_steps_per_episode=MAXS, seed=3)
+    STEPS = 90
+    pool.collect(STEPS)
+    results = pool.pop_episode_results()
+    # the twin
+    twin = GeneralsVecEnv(B, **kw)
+    obs, info = twin.reset()
+    obs = obs.copy()
+    ep_len, ep_rew = np.zeros(B, int), np.zeros(B)
+    want, want_results, it = [], [], iter(log)
+    starting = np.zeros(B, bool)
+    for k in range(STEPS):
+        acts = np.array([0 if starting[w] else next(it)[1] for w in range(B)])
+        nobs, rew, term, trunc, info = twin.step(acts)
+        nobs = nobs.copy()
+        cut = np.zeros(B, bool)
+        for w in range(B):
+            if info["reset"][w]:
+                continue
+            d = bool(term[w] or trunc[w])
+            want.append((obs[w], int(acts[w]), float(rew[w]), nobs[w], d))
+            ep_len[w] += 1
+            ep_rew[w] += rew[w]
+            if d or ep_len[w] >= MAXS:
+                want_results.append((float(ep_rew[w]), int(ep_len[w]), w))
+                cut[w] = not d
+                ep_len[w], ep_rew[w] = 0, 0.0
+        if cut.any():
+            twin.force_reset(cut)
+        starting = np.array([bool(term[w] or trunc[w]) and not info["reset"][w] for w in range(B)]) | cut
+        obs = nobs
+    assert len(buf.items) == len(want) == pool.total_env_steps
+    for i, ((s, a, r, ns, d), (ws, wa, wr, wns, wd)) in enumerate(zip(buf.items, want)):
+        assert s.shape == (9, 8, 8) and s.dtype == np.float32 and isinstance(a, int) and isinstance(d, bool), i
+        assert np.array_equal(s, ws) and a == wa and r == wr and np.array_equal(ns, wns) and d == wd, i
+    assert results == want_results and pool.total_episodes == len(results)
+    kinds = {"cut": sum(1 for r in results if r[1] == MAXS), "ended": sum(1 for r in results if r[1] < MAXS)}
+    assert kinds["cut"] > 0 and len(results) >= B
+    twin.close()
+
+
+@pytest.mark.gpu
+def test_pool_thread_over_generals_vec_env_with_batched_policy():
+    """The threaded form with one batched policy call per vector step and this package's ReplayBuffer (push_batch)."""
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    B = 256
+    rng = np.random.default_rng(0)
+
+    def policy(states, masks, workers, rngs):
+        assert states.shape == (len(workers), 9, 10, 10) and masks.shape == (len(workers), 500)
+        pick = (masks * rng.random(masks.shape)).argmax(1)       # a random valid action per env (0 if none)
+        return pick
+
+    buf = ReplayBuffer(20000)
+    pool = ParallelVecEnvPool(B, lambda n: GeneralsVecEnv(n, board_width=10, board_height=10, max_players=2, max_turns=40, seed=1, board_pool=64),
+                              policy, buf, max_steps_per_episode=25, batched_actions=True)
+    pool.start()
+    t0 = time.time()
+    while pool.total_episodes < 2 * B and time.time() - t0 < 60:
+        assert pool.alive_workers == B
+        time.sleep(0.05)
+    pool.stop(join_timeout=10.0)
+    assert pool.alive_workers == 0 and pool.total_episodes >= 2 * B
+    assert pool.total_env_steps == buf.total_pushed and len(buf) == min(20000, buf.total_pushed)
+    s, a, r, ns, d = buf.sample_arrays(64)
+    assert s.shape == (64, 9, 10, 10) and s.dtype == np.float32 and ns.shape == s.shape and d.dtype == bool
+    res = pool.pop_episode_results()
+    assert len(res) >= 2 * B and {w for _, _, w in res} == set(range(B)) and max(l for _, l, _ in res) <= 25
+    assert pool.pop_episode_results() == []

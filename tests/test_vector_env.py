@@ -1,8 +1,10 @@
-"""The drop-in vector env against a scalar, line-by-line restatement of the
-reference's python/generals_gym/generals_env.py helpers and the server's proto fog rules
-(internal/grpc/gameserver/server.go:526-582).  The reference env itself cannot run here (needs
-gymnasium and a live Go server), so the restatement below is the checker; states come from the
-CPU oracle (CPU tests) and from the HIP engine (-m gpu)."""
+"""The drop-in vector env.  Two layers of checker, both test infrastructure:
+  1. a scalar, line-by-line restatement of python/generals_gym/generals_env.py's helpers and of the server's proto fog
+     rules (internal/grpc/gameserver/server.go:526-582) - this file;
+  2. its batched numpy form + GeneralsEnv.step's bookkeeping (tests/_gym_reference.py: NumpyReferenceVecEnv), pinned to (1)
+     here on CPU with states from the oracle.
+The product (GeneralsVecEnv: the HIP gym kernels, one launch per step) is compared with (2) output for output under -m gpu.
+The reference env itself cannot run here (needs gymnasium and a live Go server): parity unpinned beyond its source text."""
 import math
 
 import numpy as np
@@ -10,7 +12,7 @@ import pytest
 
 import _harness as H
 import _oracle as O
-from generalsreinforcementlearning_amd import vector_env as V
+import _gym_reference as G
 
 DIRS = [(0, -1), (1, 0), (0, 1), (-1, 0)]
 
@@ -131,17 +133,17 @@ def test_pure_functions_match_scalar_restatement():
         if k % 8 != 0:
             continue
         st, vis, fog = _views(ora, B, w, h, 0)
-        view = V.proto_view(st["owner"], st["army"], st["type"], vis, fog)
+        view = G.proto_view(st["owner"], st["army"], st["type"], vis, fog)
         tc = np.full(B, k + 1)
-        obs = V.build_observation(view, 0, tc, 50, w, h)
-        mask = V.valid_actions_mask(view, 0, w, h)
+        obs = G.build_observation(view, 0, tc, 50, w, h)
+        mask = G.valid_actions_mask(view, 0, w, h)
         for e in range(B):
             tiles = ref_proto_tiles(st["owner"][e], st["army"][e], st["type"][e], vis[e], fog[e])
             assert np.array_equal(obs[e], ref_get_observation(tiles, w, h, 0, k + 1, 50)), (k, e)
             assert np.array_equal(mask[e], ref_valid_mask(tiles, w, h, 0)), (k, e)
         stats = {f: st[f] for f in ("done", "winner", "alive", "army_count", "tile_count")}
         if prev is not None:
-            r = V.calculate_reward(prev, stats, 0)
+            r = G.calculate_reward(prev, stats, 0)
             for e in range(B):
                 assert r[e] == ref_reward(prev, stats, e, 0), (k, e)
         prev = stats
@@ -151,7 +153,7 @@ def test_pure_functions_match_scalar_restatement():
 def test_decode_actions_matches_reference_quirk():
     w, h = 6, 4
     acts = np.arange(w * h * 5)
-    fx, fy, tx, ty, half, d = V.decode_actions(acts, w, h)
+    fx, fy, tx, ty, half, d = G.decode_actions(acts, w, h)
     for a in acts:
         assert (fx[a], fy[a], tx[a], ty[a], bool(half[a])) == ref_decode(int(a), w, h), a
 
@@ -224,19 +226,43 @@ def _episode_flow(env):
     env.close()
 
 
-def test_vector_env_episode_flow_on_oracle_engine(monkeypatch):
-    monkeypatch.setattr(V, "VecEngine", OracleBackedEngine)
-    _episode_flow(V.GeneralsVecEnv(64, board_width=8, board_height=8, max_players=2, max_turns=40, seed=3))
+def test_reference_env_episode_flow_on_oracle_engine():
+    """The checker's own episode flow, on the CPU oracle."""
+    _episode_flow(G.NumpyReferenceVecEnv(OracleBackedEngine(64, 8, 8, 2), 64, 8, 8, max_players=2, max_turns=40, seed=3))
+
+
+def _hip_reference_env(num_envs, board_width, board_height, max_players=2, fog_of_war=True, max_turns=500, seed=0, board_pool=1024):
+    """NumpyReferenceVecEnv over a HIP VecEngine: same boards, same pool, same opponents as GeneralsVecEnv with these arguments."""
+    import generalsreinforcementlearning_amd as g
+    eng = g.VecEngine(num_envs, board_width, board_height, max_players, fog_of_war=fog_of_war, auto_reset=True)
+    return G.NumpyReferenceVecEnv(eng, num_envs, board_width, board_height, max_players=max_players, fog_of_war=fog_of_war, max_turns=max_turns,
+                                  seed=seed, board_pool=board_pool)
 
 
 @pytest.mark.gpu
 def test_vector_env_api_and_episode_flow():
-    _episode_flow(V.GeneralsVecEnv(64, board_width=8, board_height=8, max_players=2, max_turns=40, seed=3))
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    _episode_flow(GeneralsVecEnv(64, board_width=8, board_height=8, max_players=2, max_turns=40, seed=3))
+
+
+def test_vector_env_needs_a_gpu_and_has_no_host_path():
+    """There is one execution path; without a GPU construction fails loudly (no silent numpy fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from generalsreinforcementlearning_amd import GvecError
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    with pytest.raises(GvecError):
+        GeneralsVecEnv(4, board_width=8, board_height=8)
+    import generalsreinforcementlearning_amd.vector_env as V
+    for name in ("proto_view", "build_observation", "valid_actions_mask", "decode_actions", "calculate_reward"):
+        assert not hasattr(V, name), f"{name}: the numpy checker must not live in the product"
 
 
 @pytest.mark.gpu
 def test_vector_env_matches_scalar_restatement_on_hip_states():
-    env = V.GeneralsVecEnv(32, board_width=10, board_height=10, max_players=2, max_turns=100, seed=9)
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    env = GeneralsVecEnv(32, board_width=10, board_height=10, max_players=2, max_turns=100, seed=9)
     obs, info = env.reset()
     rng = np.random.default_rng(1)
     for k in range(40):
@@ -296,8 +322,9 @@ def test_device_vector_env_equals_host_vector_env(fog, P):
     every output of every step, bit for bit - invalid actions, half moves, terminations, truncations and re-deals included."""
     import torch
     kw = dict(board_width=9, board_height=8, max_players=P, fog_of_war=fog, max_turns=30, seed=5, board_pool=64)
-    host = V.GeneralsVecEnv(48, numpy_reference=True, **kw)
-    dev = V.GeneralsVecEnv(48, device_outputs=True, **kw)
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    host = _hip_reference_env(48, **kw)
+    dev = GeneralsVecEnv(48, device_outputs=True, **kw)
     ho, hi = host.reset()
     do, di = dev.reset()
     assert do.is_cuda and do.dtype == torch.float32 and di["valid_actions_mask"].dtype == torch.bool
@@ -334,13 +361,13 @@ def test_device_vector_env_equals_host_vector_env(fog, P):
 
 
 @pytest.mark.gpu
-def test_default_numpy_mode_runs_on_the_gym_kernels_and_equals_the_reference_mode():
+def test_default_numpy_mode_runs_on_the_gym_kernels_and_equals_the_reference_env():
     """The default mode (numpy in / numpy out) is the device path plus pinned D2H copies: same values, dtypes and
-    shapes as the numpy_reference mode, step by step."""
+    shapes as the numpy reference env (tests/_gym_reference.py), step by step."""
     kw = dict(board_width=10, board_height=10, max_players=3, max_turns=25, seed=11, board_pool=32)
-    ref = V.GeneralsVecEnv(40, numpy_reference=True, **kw)
-    fast = V.GeneralsVecEnv(40, **kw)
-    assert fast._via_kernels and not ref._via_kernels
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    ref = _hip_reference_env(40, **kw)
+    fast = GeneralsVecEnv(40, **kw)
     ro, ri = ref.reset()
     fo, fi = fast.reset()
     rng = np.random.default_rng(4)
@@ -385,3 +412,81 @@ def test_gym_observation_log_channel_is_numpys_float64_log():
         got = obs[:, 2].cpu().numpy()
         want = (np.log(army.astype(np.int64) + 1) / 10.0).astype(np.float32)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,P,fog", [(9, 8, 2, True), (20, 20, 4, True), (12, 13, 3, False), (25, 25, 4, True), (32, 32, 8, True)],
+                         ids=["9x8_p2", "20x20_p4", "12x13_p3_nofog", "25x25_p4", "32x32_p8"])
+def test_gym_step_equals_the_four_call_composition(w, h, P, fog):
+    """gvec_gym_step (ONE launch) == gvec_agent_actions -> gvec_gym_actions -> gvec_step -> gvec_gym_finish_step on a twin
+    engine: every output of every step bit for bit, and the two engines' states at the end - over every register layout of
+    the step kernel, with invalid / out-of-range / half-move actions, terminations, truncations and re-deals."""
+    import torch
+    import generalsreinforcementlearning_amd as g
+    from generalsreinforcementlearning_amd._lib import check
+    B, max_turns, n = 64, 25, w * h
+    dev = torch.device("cuda")
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+
+    class Side:
+        def __init__(self):
+            self.e = g.VecEngine(B, w, h, P, fog_of_war=fog, auto_reset=True, stream=torch.cuda.current_stream().cuda_stream)
+            self.e.reset_generated(77)
+            self.e.build_board_pool(16, 5)
+            self.turn, self.obs, self.mask = z(B, torch.int64), z((B, 9, n), torch.float32), z((B, n * 5), torch.uint8)
+            self.out = {k: z(B, dt) for k, dt in (("reward", torch.float64), ("terminated", torch.uint8), ("truncated", torch.uint8),
+                                                  ("winner", torch.int8), ("needs_reset", torch.uint8), ("turn_out", torch.int64),
+                                                  ("played", torch.uint8), ("invalid", torch.uint8), ("error", torch.uint8))}
+            self.resetting = z(B, torch.uint8)
+            self.acts = z((B, P, 8), torch.uint8)
+            e = self.e
+            check(e.L.gvec_gym_observe(e.h, 0, self.turn.data_ptr(), max_turns, self.obs.data_ptr(), self.mask.data_ptr(), None, None, None))
+
+        def outputs(self):
+            torch.cuda.synchronize()
+            d = {k: v.cpu().numpy().copy() for k, v in self.out.items()}
+            d["obs"], d["mask"], d["turn"] = self.obs.cpu().numpy().view(np.uint32).copy(), self.mask.cpu().numpy().copy(), self.turn.cpu().numpy().copy()
+            return d
+
+    one, four = Side(), Side()
+    rng = np.random.default_rng(8)
+    seen = {"term": 0, "trunc": 0, "invalid": 0, "error": 0, "reset": 0}
+    for k in range(120):
+        mask = one.mask.cpu().numpy().astype(bool)
+        acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in mask], np.int64)
+        if k % 4 == 1:
+            acts[:5] = [int(np.flatnonzero(~m)[rng.integers(0, 10)]) for m in mask[:5]]
+            acts[5], acts[6] = -7, n * 5 + 3
+        if k % 3 == 0:
+            for e_ in range(8, 24):
+                hm = np.flatnonzero(mask[e_][4::5])
+                if len(hm):
+                    acts[e_] = int(hm[rng.integers(0, len(hm))]) * 5 + 4
+        ta = torch.from_numpy(acts).to(dev)
+        seed = 1000 * k + 3
+        o, e = one.out, one.e
+        prev_mask_four = four.mask.clone()
+        check(e.L.gvec_gym_step(e.h, 0, seed, ta.data_ptr(), one.resetting.data_ptr(), one.turn.data_ptr(), max_turns, one.obs.data_ptr(),
+                                one.mask.data_ptr(), o["reward"].data_ptr(), o["terminated"].data_ptr(), o["truncated"].data_ptr(),
+                                o["winner"].data_ptr(), o["needs_reset"].data_ptr(), o["turn_out"].data_ptr(), o["played"].data_ptr(),
+                                o["invalid"].data_ptr(), o["error"].data_ptr()), "gvec_gym_step")
+        o, e = four.out, four.e
+        check(e.L.gvec_agent_actions(e.h, seed, 0, four.acts.data_ptr(), 1))
+        check(e.L.gvec_gym_actions(e.h, 0, ta.data_ptr(), prev_mask_four.data_ptr(), four.resetting.data_ptr(), four.acts.data_ptr(),
+                                   o["played"].data_ptr(), o["invalid"].data_ptr(), o["error"].data_ptr()))
+        e.step_device(four.acts.data_ptr())
+        check(e.L.gvec_gym_finish_step(e.h, 0, four.turn.data_ptr(), max_turns, four.resetting.data_ptr(), o["played"].data_ptr(),
+                                       four.obs.data_ptr(), four.mask.data_ptr(), o["reward"].data_ptr(), o["terminated"].data_ptr(),
+                                       o["truncated"].data_ptr(), o["winner"].data_ptr(), o["needs_reset"].data_ptr(), o["turn_out"].data_ptr()))
+        a, b = one.outputs(), four.outputs()
+        for f in a:
+            x, y = a[f], b[f]
+            if f == "reward":
+                x, y = x.view(np.uint64), y.view(np.uint64)
+            assert np.array_equal(x, y), (k, f, np.flatnonzero((x != y).reshape(B, -1).any(1))[:8])
+        seen["term"] += int(a["terminated"].sum()); seen["trunc"] += int(a["truncated"].sum())
+        seen["invalid"] += int(a["invalid"].sum()); seen["error"] += int(a["error"].sum()); seen["reset"] += int(one.resetting.sum().item())
+        one.resetting.copy_(one.out["needs_reset"])
+        four.resetting.copy_(four.out["needs_reset"])
+    assert seen["trunc"] > 0 and seen["invalid"] > 0 and seen["reset"] > 0
+    H.assert_states_equal(one.e.game_state(), four.e.game_state(), "gym_step vs composition")
