@@ -84,6 +84,47 @@ def test_golden_rewards(g, c):
     assert abs(float(r[0, c["player"]]) - float(exp)) <= max(c["expect"]["delta"], 0), (r, exp)
 
 
+@pytest.mark.parametrize("c", by_kind("collector"))
+def test_golden_collector(g, c):
+    """collector_test.go's vectors through the HIP experience channel, both ways a consumer can take it: VecExperienceCollector
+    (gvec_observe / gvec_serializer_mask / gvec_experience_begin / _rewards) and the compact records a rank ships
+    (gvec_experience_records -> decode_records).  The reference test swaps in a hand-built currState; here the engine is
+    poked into it.  The ABI treats an env whose Turn did not advance as "not stepped" (reward 0, record flagged void), so
+    cur.Turn = prev.Turn + 1 where the Go test leaves it alone - Turn is not what those vectors assert."""
+    import torch
+    from generalsreinforcementlearning_amd.experience import VecExperienceCollector, decode_records
+    w, h, e = c["w"], c["h"], c["expect"]
+    eng = _hand_built(g, c, c["prev"])
+    col = VecExperienceCollector(eng)
+    col.before_step()
+    acts = g.make_actions(1, 2, [(0, a["player"], a["from"][0], a["from"][1], a["to"][0], a["to"][1], a["move_all"]) for a in c["actions"]])
+    army, owner, typ = O.planes_from_tiles(w, h, c["cur"])
+    alive = np.ones((1, 2), np.uint8)
+    for p, v in c.get("alive_cur", {}).items():
+        alive[0, int(p)] = int(v)
+    eng.write_state({"army": army[None], "owner": owner[None], "type": typ[None], "alive": alive,
+                     "turn": np.array([c.get("cur_turn", 2)], np.int32)})
+    batch = col.after_step(acts)
+    slab = torch.zeros(eng.experience_record_bytes(), dtype=torch.uint8, device="cuda")
+    eng.experience_records(slab.data_ptr(), actions=acts)
+    eng.synchronize()
+    dec = decode_records(slab.cpu().numpy(), eng.experience_record_layout())
+    for b in (batch, dec):
+        assert len(b["player_id"]) == e["count"] and sorted(int(p) for p in b["player_id"]) == e["player_ids"]
+        if "turn" in e:
+            assert int(b["turn"][0]) == e["turn"]
+        if "done" in e:
+            assert bool(b["done"][0]) == e["done"]
+        if "tensor_shape" in e:
+            assert list(np.asarray(b["state"][0]).shape) == e["tensor_shape"] == list(np.asarray(b["next_state"][0]).shape)
+            assert len(b["action_mask"][0]) == e["mask_len"]
+        if "reward" in e:
+            assert b["reward"].dtype == np.float32 and b["reward"][0] == np.float32(e["reward"])
+    assert all(dec["valid"])
+    d = col.as_dicts(batch)[0]
+    assert set(d) >= {"experience_id", "game_id", "player_id", "turn", "state", "action", "reward", "next_state", "done", "action_mask"}
+
+
 @pytest.mark.parametrize("name,B,pattern,fog", [("20x20_p4", 128, [(20, 20, 4)], True), ("mixed", 96, [(10, 10, 2), (15, 15, 3), (20, 20, 4)], True),
                                                ("10x10_fog_off", 128, [(10, 10, 2)], False), ("tiny", 48, [(3, 3, 2), (5, 7, 3), (8, 8, 2)], True)],
                          ids=lambda v: v if isinstance(v, str) else None)

@@ -118,6 +118,41 @@ class _HipEngineAdapter:
         return int(self.st("general_idx")["general_idx"][0, p])
 
 
+@pytest.mark.parametrize("c", by_kind("board_idx"))
+def test_golden_board_idx(g, c):
+    """core/board_test.go TestBoard_Idx through the ABI: a gvec_step move FROM (x, y) is accepted exactly when the player's
+    army lies at the tile index the reference expects for (x, y), and is ErrNotOwned for every other index."""
+    w, h = c["w"], c["h"]
+    n = w * h
+    for x, y, idx in c["xy_idx"]:
+        eng = g.VecEngine(n, w, h, 2, fog_of_war=False)          # env `at`: the army sits at index `at`
+        army, owner, typ = np.zeros((n, n), np.int32), np.full((n, n), -1, np.int8), np.zeros((n, n), np.uint8)
+        for at in range(n):
+            army[at, at], owner[at, at], typ[at, at] = 5, 0, 1      # both players hold a general: the game is live
+            far = n - 1 if at != n - 1 else 0
+            army[at, far], owner[at, far], typ[at, far] = 3, 1, 1
+        eng.reset(army, owner, typ)
+        tx, ty = (x + 1, y) if x + 1 < w else (x - 1, y)
+        err = eng.step(g.make_actions(n, 2, [(at, 0, x, y, tx, ty, True) for at in range(n)]))
+        want = np.full(n, 3, np.int32)
+        want[idx] = 0
+        assert np.array_equal(err, want), (x, y, idx, err)
+
+
+@pytest.mark.parametrize("c", by_kind("board_xy"))
+def test_golden_board_xy(g, c):
+    """core/board_test.go TestBoard_XY as the fog update uses it: what a player sees around its only tile, at index idx, is
+    the 3x3 centred on the reference's (x, y)."""
+    from test_oracle_golden import fog_square, xy_board
+    w, h = c["w"], c["h"]
+    for idx, x, y in c["idx_xy"]:
+        army, owner, typ = O.planes_from_tiles(w, h, xy_board(c, idx))
+        eng = g.VecEngine(1, w, h, 2, fog_of_war=True)
+        eng.reset(army[None], owner[None], typ[None])
+        vis, _ = eng.compute_player_visibility(0)
+        assert sorted(np.flatnonzero(vis[0])) == fog_square(x, y, w, h), (idx, x, y)
+
+
 @pytest.mark.parametrize("c", [p for p in by_kind("engine") if "production_turn" not in p.id])
 def test_golden_engine(g, c):
     a = _HipEngineAdapter(g, c)

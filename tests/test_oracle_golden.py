@@ -283,6 +283,72 @@ def test_city_changes(c):
     assert (g.value, l.value) == (c["expect"]["gained"], c["expect"]["lost"])
 
 
+def _neighbour(x, y, w, h):
+    return (x + 1, y) if x + 1 < w else (x - 1, y)
+
+
+@pytest.mark.parametrize("c", by_kind("board_idx"))
+def test_board_idx(c):
+    """Board.Idx (core/board.go:108): a move FROM (x, y) reads the tile at Idx(x, y) - it validates only when the player's army
+    sits at the index the reference test expects (core/action.go:82-89), and fails ErrNotOwned anywhere else."""
+    L, w, h = O.lib(), c["w"], c["h"]
+    for x, y, idx in c["xy_idx"]:
+        for at in range(w * h):
+            b = L.ora_board_new(w, h)
+            b.contents.t[at].owner, b.contents.t[at].army = 0, 5
+            tx, ty = _neighbour(x, y, w, h)
+            rc = L.ora_validate(b, C.byref(O.Move(0, x, y, tx, ty, 1)), 0)
+            assert rc == (0 if at == idx else 3), (x, y, idx, at, rc)
+            L.ora_board_free(b)
+
+
+def fog_square(x, y, w, h):
+    return sorted(yy * w + xx for yy in range(max(0, y - 1), min(h, y + 2)) for xx in range(max(0, x - 1), min(w, x + 2)))
+
+
+def xy_board(c, idx):
+    """P0's general at tile `idx`, P1's in the corner farthest from it."""
+    w, h = c["w"], c["h"]
+    far = (0 if (idx % w) * 2 >= w else w - 1) + w * (0 if (idx // w) * 2 >= h else h - 1)
+    return [{"x": idx % w, "y": idx // w, "owner": 0, "army": 5, "type": 1}, {"x": far % w, "y": far // w, "owner": 1, "army": 5, "type": 1}]
+
+
+@pytest.mark.parametrize("c", by_kind("board_xy"))
+def test_board_xy(c):
+    """Board.XY (core/board.go:111-113) as the fog update uses it (visibility_optimized.go:101,120,133,154): the 3x3 a
+    player sees around its only tile, at index idx, is centred on the (x, y) the reference test expects."""
+    for idx, x, y in c["idx_xy"]:
+        eng = O.OracleEngine(c["w"], c["h"], 2, xy_board(c, idx), fog=True)
+        vis, _ = eng.player_visibility(0)
+        assert sorted(np.flatnonzero(vis)) == fog_square(x, y, c["w"], c["h"]), (idx, x, y)
+
+
+@pytest.mark.parametrize("c", by_kind("collector"))
+def test_collector_vectors(c):
+    """SimpleCollector.OnStateTransition's per-experience fields from the oracle's pieces (collector.go:41-56)."""
+    prev = experience_engine(c, c["prev"])
+    cur = experience_engine(c, c["cur"], alive=c.get("alive_cur"))
+    if "cur_turn" in c:
+        cur.L.ora_engine_set_turn(cur.e, c["cur_turn"])
+    e, n = c["expect"], c["w"] * c["h"]
+    exps = []
+    for a in c["actions"]:                               # one experience per player that submitted an action (:33-37)
+        p = a["player"]
+        exps.append({"player_id": p, "turn": cur.turn, "state": prev.state_to_tensor(p), "next_state": cur.state_to_tensor(p),
+                     "mask": prev.serializer_mask(p), "reward": np.float32(O.lib().ora_calculate_reward(prev.e, cur.e, p)),
+                     "done": sum(cur.alive(q) for q in range(2)) <= 1})   # GameState.IsGameOver (state.go:73-82)
+    assert len(exps) == e["count"] and sorted(x["player_id"] for x in exps) == e["player_ids"]
+    x = exps[0]
+    if "turn" in e:
+        assert x["turn"] == e["turn"]
+    if "done" in e:
+        assert x["done"] == e["done"]
+    if "tensor_shape" in e:
+        assert len(x["state"]) == len(x["next_state"]) == int(np.prod(e["tensor_shape"])) and len(x["mask"]) == e["mask_len"]
+    if "reward" in e:
+        assert x["reward"] == np.float32(e["reward"])                      # assert.Equal(float32(1.0), ...): exact
+
+
 def test_oracle_is_clean_under_sanitizers():
     """address/UB sanitizers on the CPU build (GPU ASan is not available on this pool)."""
     import shutil, subprocess
