@@ -38,6 +38,10 @@ SYMBOLS = {
     "gvec_config_default": (_i32, [C.POINTER(Config)]),
     "gvec_create": (_i32, [C.POINTER(Config), C.POINTER(_vp)]),
     "gvec_destroy": (_i32, [_vp]),
+    "gvec_create_sharded": (_i32, [C.POINTER(Config), C.POINTER(C.c_int32), _i32, C.POINTER(_vp)]),
+    "gvec_num_shards": (_i32, [_vp]),
+    "gvec_shard": (_i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gvec_gather_experience_records": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gvec_set_stream": (_i32, [_vp, _vp]),
     "gvec_synchronize": (_i32, [_vp]),
     "gvec_last_error": (C.c_char_p, []),

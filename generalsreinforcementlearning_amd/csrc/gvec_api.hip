@@ -3,10 +3,16 @@
 // gfx950 kernels and fails with GVEC_E_NO_DEVICE when there is no GPU.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "gvec_launch.hpp"
@@ -64,6 +70,65 @@ struct gvec_handle {
   static constexpr int kStageSlots = 24;
   void* stage_ptr[kStageSlots] = {};
   size_t stage_cap[kStageSlots] = {};
+  // ---- sharding (gvec_create_sharded) ----
+  int env_base = 0;                 // a shard's first env within the sharded batch: keys its agent / pool / map draws
+  struct ShardWorker;
+  std::vector<std::unique_ptr<ShardWorker>> shards;   // non-empty: this handle owns no device memory, only its shards
+  bool sharded() const { return !shards.empty(); }
+};
+
+// One worker thread per shard: every call on a sharded handle posts one task per shard and waits for all of them, so the
+// shards' host copies, launches and synchronisations run concurrently (a GVEC_MEM_HOST call on a single-device handle ends
+// in a stream synchronise; calling the shards one after the other would serialise the devices).  A child handle is only
+// ever touched by its own worker: the "not thread-safe per handle" rule holds for every one of them.
+struct gvec_handle::ShardWorker {
+  gvec_handle* h = nullptr;   // a plain single-device handle
+  int begin = 0, n = 0;       // envs [begin, begin + n) of the sharded batch
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int32_t()> task;
+  bool has_task = false, done = false, quit = false;
+  int32_t rc = 0;
+  std::string err;
+
+  void run() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return has_task || quit; });
+      if (quit) return;
+      std::function<int32_t()> f = std::move(task);
+      has_task = false;
+      lk.unlock();
+      const int32_t r = f();
+      const char* e = gvec_last_error();   // this thread's own message
+      lk.lock();
+      rc = r;
+      err = (r < 0 && e) ? e : "";
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void post(std::function<int32_t()> f) {
+    std::lock_guard<std::mutex> lk(mu);
+    task = std::move(f);
+    has_task = true;
+    done = false;
+    cv.notify_all();
+  }
+  int32_t wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+    return rc;
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
 };
 
 namespace {
@@ -129,6 +194,7 @@ StepArgs base_args(const gvec_handle* h) {
   a.agent_half = h->agent_half;
   a.pool_seed_lo = (uint32_t)h->pool_seed;
   a.pool_seed_hi = (uint32_t)(h->pool_seed >> 32);
+  a.env_base = h->env_base;
   if (h->cfg.auto_reset && h->pool_size > 0) a.flags |= KF_AUTORESET;
   return a;
 }
@@ -285,6 +351,136 @@ int32_t allocate_handle(gvec_handle* h, const gvec_config* cfg) {
 
 }  // namespace
 
+// =========================================================================================================================
+// Sharded handles (gvec_create_sharded): one handle over several devices, SURVEY 8(b) "one handle may span several GPUs".
+// Boards are independent, so shard i simply IS envs [begin_i, begin_i + n_i) of the batch (contiguous, sizes differing by
+// at most one: the shard_range rule of sharding.py), resident on its own device for the whole run; no call moves board
+// state between devices.  Every GVEC_MEM_HOST entry point fans out to the shards with the caller's arrays offset to the
+// shard's range, all shards working at once on their own threads and streams.  Because a shard folds its offset into the
+// agent / pool / map keys (env_base), the batch plays the same games whatever the number of shards:
+// tests/test_hip_sharded.py holds a 3-shard handle against a single-device one bit for bit.
+// Entry points that take DEVICE pointers belong to one device: use them on gvec_shard(h, i).
+// =========================================================================================================================
+namespace sharded {
+
+template <typename F>  // F(gvec_handle* child, int begin, int n) -> int32_t; copied into every shard's task
+int32_t fan(gvec_handle* h, F f) {
+  for (auto& w : h->shards) {
+    gvec_handle::ShardWorker* wp = w.get();
+    wp->post([f, wp]() { return f(wp->h, wp->begin, wp->n); });
+  }
+  int32_t rc = GVEC_OK;
+  for (auto& w : h->shards) {
+    const int32_t r = w->wait();
+    if (r < 0 && rc >= 0) {
+      rc = r;
+      set_err("shard of envs [%d, %d) on device %d: %s", w->begin, w->begin + w->n, w->h ? w->h->cfg.device : -1, w->err.c_str());
+    }
+  }
+  return rc;
+}
+
+int32_t host_only(int32_t mem, const char* what) {
+  if (mem == GVEC_MEM_HOST) return GVEC_OK;
+  set_err("%s with device pointers on a sharded handle: device memory belongs to one device - call it on gvec_shard(h, i)", what);
+  return GVEC_E_INVALID;
+}
+int32_t unsupported(const char* what) {
+  set_err("%s works on one device: call it on gvec_shard(h, i)", what);
+  return GVEC_E_INVALID;
+}
+
+// the part of a caller's view that covers `skip` envs further on
+gvec_state_view offset_view(const gvec_state_view& v, size_t skip, int stride, int maxp) {
+  gvec_state_view o = v;
+  const size_t t = skip * (size_t)stride, p = skip * (size_t)maxp;
+#define GVEC_OFF(field, count) if (o.field) o.field += (count)
+  GVEC_OFF(army, t); GVEC_OFF(owner, t); GVEC_OFF(type, t); GVEC_OFF(visible, t); GVEC_OFF(listed, t); GVEC_OFF(changed, t);
+  GVEC_OFF(vis_changed, t); GVEC_OFF(turn, skip); GVEC_OFF(done, skip); GVEC_OFF(winner, skip); GVEC_OFF(width, skip);
+  GVEC_OFF(height, skip); GVEC_OFF(players, skip); GVEC_OFF(alive, p); GVEC_OFF(army_count, p); GVEC_OFF(tile_count, p);
+  GVEC_OFF(general_idx, p);
+#undef GVEC_OFF
+  return o;
+}
+
+// envs [env_begin, env_begin + n) of the batch, split over the shards: f(child, local_begin, count, envs before this piece)
+template <typename F>
+int32_t fan_range(gvec_handle* h, int32_t env_begin, int32_t n, F f) {
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  return fan(h, [=](gvec_handle* c, int begin, int cn) -> int32_t {
+    const int lo = env_begin > begin ? env_begin : begin, hi = (env_begin + n) < (begin + cn) ? (env_begin + n) : (begin + cn);
+    if (hi <= lo) return GVEC_OK;
+    return f(c, lo - begin, hi - lo, (size_t)(lo - env_begin));
+  });
+}
+
+int32_t reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int32_t* army, const int8_t* owner, const uint8_t* type,
+              const int32_t* width, const int32_t* height, const int32_t* players, int32_t mem) {
+  RET_IF(host_only(mem, "gvec_reset"));
+  const size_t st = (size_t)h->stride;
+  if (!env_ids) {
+    return fan_range(h, 0, n, [=](gvec_handle* c, int lb, int cnt, size_t skip) {
+      return gvec_reset(c, nullptr, cnt, army + skip * st, owner + skip * st, type + skip * st, width + skip, height + skip, players + skip, GVEC_MEM_HOST);
+    });
+  }
+  // explicit ids: every shard gets the rows addressed to it, in the caller's order
+  struct Part {
+    std::vector<int32_t> ids, w, hh, p, army;
+    std::vector<int8_t> owner;
+    std::vector<uint8_t> type;
+  };
+  auto parts = std::make_shared<std::vector<Part>>(h->shards.size());
+  for (int i = 0; i < n; ++i) {
+    const int e = env_ids[i];
+    if (e < 0 || e >= h->cfg.num_envs) return GVEC_E_RANGE;
+    size_t k = 0;
+    while (e >= h->shards[k]->begin + h->shards[k]->n) ++k;
+    Part& P = (*parts)[k];
+    P.ids.push_back(e - h->shards[k]->begin);
+    P.w.push_back(width[i]);
+    P.hh.push_back(height[i]);
+    P.p.push_back(players[i]);
+    P.army.insert(P.army.end(), army + i * st, army + (i + 1) * st);
+    P.owner.insert(P.owner.end(), owner + i * st, owner + (i + 1) * st);
+    P.type.insert(P.type.end(), type + i * st, type + (i + 1) * st);
+  }
+  std::vector<int> index_of(h->cfg.num_envs + 1, 0);
+  for (size_t k = 0; k < h->shards.size(); ++k) index_of[h->shards[k]->begin] = (int)k;
+  return fan(h, [parts, index_of](gvec_handle* c, int begin, int) -> int32_t {
+    const Part& P = (*parts)[index_of[begin]];
+    if (P.ids.empty()) return GVEC_OK;
+    return gvec_reset(c, P.ids.data(), (int32_t)P.ids.size(), P.army.data(), P.owner.data(), P.type.data(), P.w.data(), P.hh.data(), P.p.data(),
+                      GVEC_MEM_HOST);
+  });
+}
+
+int32_t gather_records(gvec_handle* h, int32_t local_begin, int32_t n, int32_t env_id_base, int32_t mem, int32_t dst_device, void* dst) {
+  if (!dst || n < 0 || local_begin < 0) return GVEC_E_INVALID;
+  for (auto& w : h->shards)
+    if (local_begin + n > w->n) {
+      set_err("gvec_gather_experience_records: envs [%d, %d) of every shard, but a shard holds %d", local_begin, local_begin + n, w->n);
+      return GVEC_E_RANGE;
+    }
+  if (n == 0) return GVEC_OK;
+  const size_t rec = (size_t)gvec_experience_record_bytes(h);
+  std::vector<int> index_of(h->cfg.num_envs + 1, 0);
+  for (size_t k = 0; k < h->shards.size(); ++k) index_of[h->shards[k]->begin] = (int)k;
+  return fan(h, [=](gvec_handle* c, int begin, int) -> int32_t {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    DevBuf stage(c, gvec_handle::kStageSlots - 1);
+    HIPCHK(stage.alloc((size_t)n * rec));
+    RET_IF(gvec_experience_records(c, nullptr, GVEC_MEM_DEVICE, local_begin, n, env_id_base + begin, stage.p));
+    char* to = reinterpret_cast<char*>(dst) + (size_t)index_of[begin] * n * rec;
+    if (mem == GVEC_MEM_HOST) HIPCHK(hipMemcpyAsync(to, stage.p, (size_t)n * rec, hipMemcpyDeviceToHost, c->stream));
+    else if (dst_device == c->cfg.device) HIPCHK(hipMemcpyAsync(to, stage.p, (size_t)n * rec, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpyPeerAsync(to, dst_device, stage.p, c->cfg.device, (size_t)n * rec, c->stream));   // over xGMI
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GVEC_OK;
+  });
+}
+
+}  // namespace sharded
+
 extern "C" {
 
 int32_t gvec_abi_version(void) { return GVEC_ABI_VERSION; }
@@ -308,6 +504,115 @@ int32_t gvec_config_default(gvec_config* cfg) {
   return GVEC_OK;
 }
 
+// the sizes a handle derives from its config (shared by plain and sharded handles)
+static bool set_geometry(gvec_handle* h, const gvec_config* cfg) {
+  h->cfg = *cfg;
+  h->stride = cfg->max_width * cfg->max_height;
+  h->maxp = cfg->max_players;
+  if (!pick_variant(cfg->max_players, h->stride, &h->var)) {
+    set_err("no kernel variant for %d players / %d tiles", cfg->max_players, h->stride);
+    return false;
+  }
+  // dwords per flat bit-plane: 2*nslot-1 or 2*nslot, so that the step kernel can be compiled for it
+  h->fd = (h->stride <= 32 * (2 * h->var.nslot - 1)) ? 2 * h->var.nslot - 1 : 2 * h->var.nslot;
+  h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 13) * h->fd, 4);  // Planes<MAXP>::COUNT planes of fd dwords
+  h->army_dw = h->var.nslot * 64;
+  h->mask_bytes = 16 * h->fd;  // four direction bit-planes of fd dwords per player
+  h->mask_dw = h->mask_bytes / 4;
+  h->stream = nullptr;
+  return true;
+}
+
+int32_t gvec_create_sharded(const gvec_config* cfg, const int32_t* devices, int32_t num_devices, gvec_handle** out) {
+  if (!cfg || !out || !devices || num_devices < 1 || num_devices > 64) return GVEC_E_INVALID;
+  *out = nullptr;
+  if (cfg->num_envs < num_devices) {
+    set_err("gvec_create_sharded: %d envs over %d shards", cfg->num_envs, num_devices);
+    return GVEC_E_INVALID;
+  }
+  RET_IF(ensure_device());
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  for (int i = 0; i < num_devices; ++i)
+    if (devices[i] < 0 || devices[i] >= ndev) {
+      set_err("gvec_create_sharded: device %d of %d", devices[i], ndev);
+      return GVEC_E_INVALID;
+    }
+  gvec_handle* h = new (std::nothrow) gvec_handle();
+  if (!h) return GVEC_E_INVALID;
+  gvec_config top = *cfg;
+  top.device = devices[0];
+  if (cfg->abi_version != GVEC_ABI_VERSION || !set_geometry(h, &top)) {
+    delete h;
+    return GVEC_E_INVALID;
+  }
+  h->legal_valid = true;
+  const int base = cfg->num_envs / num_devices, rem = cfg->num_envs % num_devices;   // sharding.shard_range
+  for (int i = 0; i < num_devices; ++i) {
+    auto w = std::make_unique<gvec_handle::ShardWorker>();
+    w->n = base + (i < rem ? 1 : 0);
+    w->begin = i * base + (i < rem ? i : rem);
+    gvec_handle::ShardWorker* wp = w.get();
+    w->th = std::thread([wp] { wp->run(); });
+    h->shards.push_back(std::move(w));
+  }
+  for (int i = 0; i < num_devices; ++i) {
+    gvec_handle::ShardWorker* wp = h->shards[i].get();
+    gvec_config c = *cfg;
+    c.num_envs = wp->n;
+    c.device = devices[i];
+    wp->post([wp, c, devices, num_devices, i]() -> int32_t {
+      const int32_t rc = gvec_create(&c, &wp->h);
+      if (rc != GVEC_OK) return rc;
+      wp->h->env_base = wp->begin;
+      for (int j = 0; j < num_devices; ++j)   // direct xGMI copies for the record gather (best effort: already on / same device fail harmlessly)
+        if (devices[j] != devices[i]) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+          (void)hipGetLastError();
+        }
+      return GVEC_OK;
+    });
+  }
+  int32_t rc = GVEC_OK;
+  for (auto& w : h->shards) {
+    const int32_t r = w->wait();
+    if (r < 0 && rc >= 0) {
+      rc = r;
+      set_err("shard of envs [%d, %d): %s", w->begin, w->begin + w->n, w->err.c_str());
+    }
+  }
+  if (rc != GVEC_OK) {
+    std::string keep = g_err;
+    (void)gvec_destroy(h);
+    set_err("%s", keep.c_str());
+    return rc;
+  }
+  *out = h;
+  return GVEC_OK;
+}
+
+int32_t gvec_num_shards(const gvec_handle* h) { return h ? (int32_t)h->shards.size() : GVEC_E_INVALID; }
+
+int32_t gvec_shard(gvec_handle* h, int32_t i, gvec_handle** child, int32_t* env_begin, int32_t* n, int32_t* device) {
+  if (!h || !h->sharded() || i < 0 || i >= (int32_t)h->shards.size()) return GVEC_E_INVALID;
+  const auto& w = h->shards[i];
+  if (child) *child = w->h;
+  if (env_begin) *env_begin = w->begin;
+  if (n) *n = w->n;
+  if (device) *device = w->h->cfg.device;
+  return GVEC_OK;
+}
+
+int32_t gvec_gather_experience_records(gvec_handle* h, int32_t shard_env_begin, int32_t n, int32_t env_id_base, int32_t mem, int32_t dst_device,
+                                       void* dst) {
+  if (!h || !h->sharded()) {
+    set_err("gvec_gather_experience_records needs a sharded handle (a plain one writes its records with gvec_experience_records)");
+    return GVEC_E_INVALID;
+  }
+  return sharded::gather_records(h, shard_env_begin, n, env_id_base, mem, dst_device, dst);
+}
+
 int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   if (!cfg || !out) return GVEC_E_INVALID;
   *out = nullptr;
@@ -326,21 +631,10 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
   HIPCHK(hipSetDevice(cfg->device));
   gvec_handle* h = new (std::nothrow) gvec_handle();
   if (!h) return GVEC_E_INVALID;
-  h->cfg = *cfg;
-  h->stride = cfg->max_width * cfg->max_height;
-  h->maxp = cfg->max_players;
-  if (!pick_variant(cfg->max_players, h->stride, &h->var)) {
+  if (!set_geometry(h, cfg)) {
     delete h;
-    set_err("no kernel variant for %d players / %d tiles", cfg->max_players, h->stride);
     return GVEC_E_INVALID;
   }
-  // dwords per flat bit-plane: 2*nslot-1 or 2*nslot, so that the step kernel can be compiled for it
-  h->fd = (h->stride <= 32 * (2 * h->var.nslot - 1)) ? 2 * h->var.nslot - 1 : 2 * h->var.nslot;
-  h->row_dw = (int)round_up((size_t)(3 * h->var.maxp + 13) * h->fd, 4);  // Planes<MAXP>::COUNT planes of fd dwords
-  h->army_dw = h->var.nslot * 64;
-  h->mask_bytes = 16 * h->fd;  // four direction bit-planes of fd dwords per player
-  h->mask_dw = h->mask_bytes / 4;
-  h->stream = nullptr;
   {
     const int32_t rc = allocate_handle(h, cfg);
     if (rc != GVEC_OK) {
@@ -355,6 +649,20 @@ int32_t gvec_create(const gvec_config* cfg, gvec_handle** out) {
 
 int32_t gvec_destroy(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    for (auto& w : h->shards) {   // each child on the thread that has been driving its device
+      gvec_handle::ShardWorker* wp = w.get();
+      wp->post([wp]() -> int32_t {
+        const int32_t r = wp->h ? gvec_destroy(wp->h) : GVEC_OK;
+        wp->h = nullptr;
+        return r;
+      });
+    }
+    for (auto& w : h->shards) (void)w->wait();
+    for (auto& w : h->shards) w->stop();
+    delete h;
+    return GVEC_OK;
+  }
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->d_legal, h->d_actions, h->d_err, h->d_status, h->d_zeros, h->d_counters,
                   h->d_snap, h->d_gym_prev, h->p_hdr, h->p_rows, h->p_army16, h->p_army32};
@@ -368,11 +676,13 @@ int32_t gvec_destroy(gvec_handle* h) {
 
 int32_t gvec_set_stream(gvec_handle* h, void* hip_stream) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_set_stream");
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return GVEC_OK;
 }
 int32_t gvec_synchronize(gvec_handle* h) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::fan(h, [](gvec_handle* c, int, int) { return gvec_synchronize(c); });
   HIPCHK(hipStreamSynchronize(h->stream));
   return GVEC_OK;
 }
@@ -388,6 +698,7 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
                    const uint8_t* type, const int32_t* width, const int32_t* height, const int32_t* players, int32_t mem) {
   if (!h || n < 0 || !army || !owner || !type || !width || !height || !players) return GVEC_E_INVALID;
   if (n == 0) return GVEC_OK;
+  if (h->sharded()) return sharded::reset(h, env_ids, n, army, owner, type, width, height, players, mem);
   if (!env_ids && n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (env_ids && mem == GVEC_MEM_HOST)
     for (int i = 0; i < n; ++i)
@@ -411,7 +722,7 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
 }
 
 static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* army16, int32_t* army32, int count, uint64_t seed,
-                             const int32_t* width, const int32_t* height, const int32_t* players) {
+                             const int32_t* width, const int32_t* height, const int32_t* players, int index_base = 0) {
   const int chunk = 65536;
   DevBuf b_army(h, 1), b_owner(h, 2), b_type(h, 3), b_w(h, 4), b_h(h, 5), b_p(h, 6), b_iw(h, 7), b_ih(h, 8), b_ip(h, 9);
   const int cn = count < chunk ? count : chunk;
@@ -445,7 +756,7 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint
     m.max_w = h->cfg.max_width;
     m.max_h = h->cfg.max_height;
     m.max_p = h->maxp;
-    m.first_index = first;
+    m.first_index = index_base + first;   // board i of a shard is board env_base + i of the batch (pool boards: no offset)
     m.seed_lo = (uint32_t)seed;
     m.seed_hi = (uint32_t)(seed >> 32);
     m.status = h->d_status;
@@ -467,14 +778,23 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint
 int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed, const int32_t* width, const int32_t* height,
                              const int32_t* players) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded())
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_reset_generated(c, seed, width ? width + begin : nullptr, height ? height + begin : nullptr, players ? players + begin : nullptr);
+    });
   HIPCHK(hipSetDevice(h->cfg.device));
-  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->cfg.num_envs, seed, width, height, players));
+  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->cfg.num_envs, seed, width, height, players, h->env_base));
   return refresh_legal(h);
 }
 
 int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed, const int32_t* width, const int32_t* height,
                               const int32_t* players) {
   if (!h || pool_size < 1) return GVEC_E_INVALID;
+  if (h->sharded()) {  // every shard keeps its own copy of the same pool (board j is keyed by (seed, j) alone)
+    const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int, int) { return gvec_build_board_pool(c, pool_size, seed, width, height, players); });
+    if (rc == GVEC_OK) h->pool_size = pool_size;
+    return rc;
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->p_hdr) (void)hipFree(h->p_hdr);
@@ -498,6 +818,13 @@ int32_t gvec_build_board_pool(gvec_handle* h, int32_t pool_size, uint64_t seed, 
 
 int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err, uint8_t* legal_bits, int32_t mem) {
   if (!h || !actions) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_step"));
+    const size_t mp = (size_t)h->maxp, mb = (size_t)h->maxp * h->mask_bytes;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_step(c, actions + begin * mp, err ? err + begin : nullptr, legal_bits ? legal_bits + begin * mb : nullptr, GVEC_MEM_HOST);
+    });
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t B = (size_t)h->cfg.num_envs;
   StepArgs a = base_args(h);
@@ -529,6 +856,11 @@ int32_t gvec_step(gvec_handle* h, const gvec_action* actions, int32_t* err, uint
 
 int32_t gvec_legal_mask(gvec_handle* h, uint8_t* legal_bits, int32_t mem) {
   if (!h || !legal_bits) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_legal_mask"));
+    const size_t mb = (size_t)h->maxp * h->mask_bytes;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_legal_mask(c, legal_bits + begin * mb, GVEC_MEM_HOST); });
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->legal_valid) RET_IF(refresh_legal(h));
   const size_t bytes = (size_t)h->cfg.num_envs * h->maxp * h->mask_bytes;
@@ -609,16 +941,41 @@ static int32_t export_range(gvec_handle* h, int32_t env_begin, int32_t n, const 
 
 int32_t gvec_player_visibility(gvec_handle* h, int32_t player, uint8_t* visible, uint8_t* fog, int32_t mem) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_player_visibility"));
+    const size_t st = (size_t)h->stride;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_player_visibility(c, player, visible ? visible + begin * st : nullptr, fog ? fog + begin * st : nullptr, GVEC_MEM_HOST);
+    });
+  }
   return export_range(h, 0, h->cfg.num_envs, nullptr, player, visible, fog, mem);
 }
 
 int32_t gvec_read_state(gvec_handle* h, int32_t env_begin, int32_t n, const gvec_state_view* view, int32_t mem) {
   if (!h || !view) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_read_state"));
+    const gvec_state_view v = *view;
+    const int st = h->stride, mp = h->maxp;
+    return sharded::fan_range(h, env_begin, n, [=](gvec_handle* c, int lb, int cnt, size_t skip) {
+      const gvec_state_view o = sharded::offset_view(v, skip, st, mp);
+      return gvec_read_state(c, lb, cnt, &o, GVEC_MEM_HOST);
+    });
+  }
   return export_range(h, env_begin, n, view, -1, nullptr, nullptr, mem);
 }
 
 int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gvec_state_view* view, int32_t mem) {
   if (!h || !view) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_write_state"));
+    const gvec_state_view v = *view;
+    const int st = h->stride, mp = h->maxp;
+    return sharded::fan_range(h, env_begin, n, [=](gvec_handle* c, int lb, int cnt, size_t skip) {
+      const gvec_state_view o = sharded::offset_view(v, skip, st, mp);
+      return gvec_write_state(c, lb, cnt, &o, GVEC_MEM_HOST);
+    });
+  }
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (n == 0) return GVEC_OK;
   if (view->width || view->height || view->players) {
@@ -650,6 +1007,22 @@ int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n, const gve
 int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t fused,
                      gvec_rollout_stats* stats) {
   if (!h || turns < 0) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->cfg.num_envs + 1);   // indexed by the shard's first env
+    const bool want = stats != nullptr;
+    const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_rollout(c, turns, seed, invalid_permille, fused, want ? &(*per)[begin] : nullptr);
+    });
+    if (stats) {
+      memset(stats, 0, sizeof *stats);
+      for (auto& w : h->shards) {
+        stats->env_steps += (*per)[w->begin].env_steps;
+        stats->aborted_turns += (*per)[w->begin].aborted_turns;
+        stats->games_finished += (*per)[w->begin].games_finished;
+      }
+    }
+    return rc;
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   if (stats) {
     HIPCHK(hipMemsetAsync(h->d_counters, 0, 6 * sizeof(unsigned long long), h->stream));
@@ -686,6 +1059,10 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
 
 int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_per_65536) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    for (auto& w : h->shards) RET_IF(gvec_set_agent_mix(w->h, noop_per_65536, half_per_65536));  // host-side fields only
+    return GVEC_OK;
+  }
   if (noop_per_65536 < 0 || noop_per_65536 > 65536 || half_per_65536 < 0 || half_per_65536 > 65536) {
     set_err("gvec_set_agent_mix: thresholds must be in [0, 65536]");
     return GVEC_E_INVALID;
@@ -697,6 +1074,17 @@ int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_
 
 int32_t gvec_counters(gvec_handle* h, gvec_rollout_stats* out) {
   if (!h || !out) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->cfg.num_envs + 1);
+    const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_counters(c, &(*per)[begin]); });
+    memset(out, 0, sizeof *out);
+    for (auto& w : h->shards) {
+      out->env_steps += (*per)[w->begin].env_steps;
+      out->aborted_turns += (*per)[w->begin].aborted_turns;
+      out->games_finished += (*per)[w->begin].games_finished;
+    }
+    return rc;
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipMemsetAsync(h->d_counters, 0, 3 * sizeof(unsigned long long), h->stream));
   HIPCHK(launch_counter_sum(h->d_hdr, h->cfg.num_envs, h->d_counters, h->stream));
@@ -729,6 +1117,11 @@ int32_t gvec_step_traffic_bytes(const gvec_handle* h, int64_t* out4) {
 
 int32_t gvec_agent_actions(gvec_handle* h, uint64_t seed, int32_t invalid_permille, gvec_action* actions, int32_t mem) {
   if (!h || !actions) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_agent_actions"));
+    const size_t mp = (size_t)h->maxp;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_agent_actions(c, seed, invalid_permille, actions + begin * mp, GVEC_MEM_HOST); });
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   StepArgs a = base_args(h);
   a.seed_lo = (uint32_t)seed;
@@ -774,6 +1167,8 @@ static int32_t ensure_snapshots(gvec_handle* h) {
 
 int32_t gvec_experience_begin_range(gvec_handle* h, int32_t env_begin, int32_t n) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded())
+    return sharded::fan_range(h, env_begin, n, [](gvec_handle* c, int lb, int cnt, size_t) { return gvec_experience_begin_range(c, lb, cnt); });
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (n == 0) return GVEC_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -792,6 +1187,11 @@ int32_t gvec_experience_begin(gvec_handle* h) {
 
 int32_t gvec_experience_rewards(gvec_handle* h, float* rewards, uint8_t* done, int32_t mem) {
   if (!h || !rewards) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_experience_rewards"));
+    const size_t mp = (size_t)h->maxp;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_experience_rewards(c, rewards + begin * mp, done ? done + begin : nullptr, GVEC_MEM_HOST); });
+  }
   if (!h->d_snap) {
     set_err("gvec_experience_rewards without a preceding gvec_experience_begin");
     return GVEC_E_INVALID;
@@ -833,6 +1233,7 @@ int32_t gvec_experience_record_bytes(gvec_handle* h) {
 int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int32_t mem, int32_t env_begin, int32_t n,
                                 int32_t env_id_base, void* dst_device) {
   if (!h || !dst_device) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_experience_records (a sharded handle collects with gvec_gather_experience_records)");
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (!h->d_snap) {
     set_err("gvec_experience_records without a preceding gvec_experience_begin");
@@ -859,6 +1260,10 @@ int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int3
 
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
   if (!h) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    for (auto& w : h->shards) RET_IF(gvec_record_agent_actions(w->h, on));
+    return GVEC_OK;
+  }
   h->record_actions = on != 0;
   return GVEC_OK;
 }
@@ -885,6 +1290,7 @@ static int32_t gym_observe_impl(gvec_handle* h, int32_t player, const int64_t* t
                                 double* reward, uint8_t* done, int8_t* winner, const uint8_t* resetting, const uint8_t* played, int64_t* turn_io,
                                 int64_t* turn_out, uint8_t* terminated, uint8_t* truncated, uint8_t* needs_reset) {
   if (!h || !turn_count || !obs || !mask || player < 0 || player >= h->maxp || max_turns < 1) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_gym_observe / gvec_gym_finish_step");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->d_gym_prev) {
     HIPCHK(hipMalloc(&h->d_gym_prev, (size_t)h->cfg.num_envs * 3 * h->var.maxp * 4));
@@ -923,6 +1329,7 @@ static int32_t gym_observe_impl(gvec_handle* h, int32_t player, const int64_t* t
 int32_t gvec_gym_actions(gvec_handle* h, int32_t player, const int64_t* gym_actions, const uint8_t* mask, const uint8_t* resetting,
                          gvec_action* actions, uint8_t* played, uint8_t* invalid, uint8_t* error) {
   if (!h || !gym_actions || !mask || !actions || player < 0 || player >= h->maxp) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_gym_actions");
   HIPCHK(hipSetDevice(h->cfg.device));
   GymActArgs a;
   memset(&a, 0, sizeof a);
@@ -947,6 +1354,7 @@ int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const
                       uint8_t* truncated, int8_t* winner, uint8_t* needs_reset, int64_t* turn_out, uint8_t* played, uint8_t* invalid,
                       uint8_t* error) {
   if (!h || !gym_actions || !resetting || !turn_count || !obs || !mask || player < 0 || player >= h->maxp || max_turns < 1) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_gym_step");
   if (!(h->cfg.auto_reset && h->pool_size > 0)) {
     set_err("gvec_gym_step needs auto_reset and a board pool (gvec_build_board_pool): episodes end by re-dealing");
     return GVEC_E_INVALID;
@@ -987,6 +1395,11 @@ int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const
 
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
   if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_observe"));
+    const size_t per = (size_t)(player < 0 ? h->maxp : 1) * 9 * h->stride;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_observe(c, player, out + begin * per, GVEC_MEM_HOST); });
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t count = (size_t)h->cfg.num_envs * (player < 0 ? h->maxp : 1) * 9 * h->stride;
   DevBuf bo(h, 0);
@@ -1001,6 +1414,11 @@ int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
 
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem) {
   if (!h || !bits) return GVEC_E_INVALID;
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_serializer_mask"));
+    const size_t mb = (size_t)h->maxp * h->mask_bytes;
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_serializer_mask(c, bits + begin * mb, GVEC_MEM_HOST); });
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t bytes = (size_t)h->cfg.num_envs * h->maxp * h->mask_bytes;
   DevBuf bb(h, 0);
@@ -1039,6 +1457,7 @@ static RecordArgs record_args(gvec_handle* h, int32_t env_begin, int32_t n, void
 
 int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n, void* dst_device) {
   if (!h || !dst_device) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_export_records");
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (n == 0) return GVEC_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1048,6 +1467,7 @@ int32_t gvec_export_records(gvec_handle* h, int32_t env_begin, int32_t n, void* 
 
 int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n, const void* src_device) {
   if (!h || !src_device) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_import_records");
   if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
   if (n == 0) return GVEC_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1059,6 +1479,7 @@ int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n, const 
 
 void* gvec_device_buffer(gvec_handle* h, int32_t which) {
   if (!h) return nullptr;
+  if (h->sharded()) return nullptr;   // device memory belongs to one device: gvec_device_buffer(gvec_shard(h, i), which)
   switch (which) {
     case 0: return h->d_hdr;
     case 1: return h->d_rows;

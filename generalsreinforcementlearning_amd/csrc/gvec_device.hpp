@@ -160,6 +160,7 @@ struct StepArgs {
   uint32_t agent_noop, agent_half;  // gvec_set_agent_mix thresholds (of 65536)
   uint32_t flags, seed_lo, seed_hi, pool_seed_lo, pool_seed_hi;
   uint32_t seed_base, pool_seed_base;  // env_key_base of the two seeds: filled in by the launchers (with_seed_bases)
+  int32_t env_base;                    // host side only: this handle's first env within its sharded batch (folded into the bases)
 };
 
 // ---- army storage ------------------------------------------------------------------------

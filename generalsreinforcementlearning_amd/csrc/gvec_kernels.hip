@@ -1480,10 +1480,13 @@ static hipError_t dispatch(const Variant& v, F&& f) {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
 
+// env_key_of(base, env) = fmix32(base + env * C): a handle that is shard [env_base, env_base + B) of a larger batch
+// (gvec_create_sharded) folds its offset into the bases, and its env e then draws exactly what env env_base + e of one
+// big handle would - agent moves and pool boards alike; the kernels never see the offset.
 static inline StepArgs with_seed_bases(const StepArgs& in) {
   StepArgs a = in;
-  a.seed_base = env_key_base(a.seed_lo, a.seed_hi);
-  a.pool_seed_base = env_key_base(a.pool_seed_lo, a.pool_seed_hi);
+  a.seed_base = env_key_base(a.seed_lo, a.seed_hi) + (uint32_t)a.env_base * 0xC2B2AE3Du;
+  a.pool_seed_base = env_key_base(a.pool_seed_lo, a.pool_seed_hi) + (uint32_t)a.env_base * 0xC2B2AE3Du;
   return a;
 }
 

@@ -64,7 +64,10 @@ class VecEngine:
     """B independent engines stepped by one HIP launch (one wavefront per board)."""
 
     def __init__(self, num_envs, width, height, players, fog_of_war=True, device=0, production=(1, 1, 1),
-                 normal_growth_interval=25, auto_reset=False, stream=None, lib=None):
+                 normal_growth_interval=25, auto_reset=False, stream=None, lib=None, devices=None):
+        """devices: a list of HIP device ordinals -> ONE engine over several GPUs (gvec_create_sharded): the boards are split
+        into contiguous shards, one per listed device; every host-array method works unchanged on all B boards, device-pointer
+        methods belong to one device (`shard(i)`).  The batch plays the same games whatever the number of shards."""
         self.L = lib if lib is not None else _lib.load()
         cfg = Config()
         check(self.L.gvec_config_default(C.byref(cfg)))
@@ -73,7 +76,12 @@ class VecEngine:
         cfg.prod_general, cfg.prod_city, cfg.prod_normal = production
         cfg.normal_growth_interval = normal_growth_interval
         self.h = C.c_void_p()
-        check(self.L.gvec_create(C.byref(cfg), C.byref(self.h)), "gvec_create")
+        self._owned = True
+        if devices is not None:
+            devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            check(self.L.gvec_create_sharded(C.byref(cfg), devs, len(devices), C.byref(self.h)), "gvec_create_sharded")
+        else:
+            check(self.L.gvec_create(C.byref(cfg), C.byref(self.h)), "gvec_create")
         self.B, self.max_w, self.max_h, self.max_p = num_envs, width, height, players
         self.stride = self.L.gvec_tile_stride(self.h)
         self.mask_bytes = self.L.gvec_mask_bytes(self.h)
@@ -82,8 +90,37 @@ class VecEngine:
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
-            self.L.gvec_destroy(self.h)
+            if getattr(self, "_owned", True):      # a shard view belongs to its sharded engine
+                self.L.gvec_destroy(self.h)
             self.h = C.c_void_p()
+
+    # ---- sharded engines (gvec_create_sharded) ---------------------------------------------------------
+    def num_shards(self):
+        return self.L.gvec_num_shards(self.h)
+
+    def shard(self, i):
+        """(view, env_begin, num_envs, device): a VecEngine view of shard i for the device-pointer methods; it must not
+        outlive this engine."""
+        child, begin, n, dev = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.gvec_shard(self.h, i, C.byref(child), C.byref(begin), C.byref(n), C.byref(dev)), "gvec_shard")
+        v = object.__new__(VecEngine)
+        v.L, v.h, v._owned = self.L, child, False
+        v.B, v.max_w, v.max_h, v.max_p, v.stride, v.mask_bytes = n.value, self.max_w, self.max_h, self.max_p, self.stride, self.mask_bytes
+        return v, begin.value, n.value, dev.value
+
+    def gather_experience_records(self, n, shard_env_begin=0, env_id_base=0, dst_device_ptr=None, dst_device=0):
+        """Sharded engines: every shard's records of ITS envs [shard_env_begin, +n) to one place.  dst_device_ptr None ->
+        a host uint8 array [num_shards * n * record_bytes] is returned (each device copies over its own PCIe link);
+        else the slabs travel GPU-to-GPU into that buffer on dst_device."""
+        k = self.num_shards()
+        if dst_device_ptr is None:
+            out = np.empty(k * n * self.experience_record_bytes(), np.uint8)
+            check(self.L.gvec_gather_experience_records(self.h, shard_env_begin, n, env_id_base, MEM_HOST, 0, out.ctypes.data),
+                  "gvec_gather_experience_records")
+            return out
+        check(self.L.gvec_gather_experience_records(self.h, shard_env_begin, n, env_id_base, MEM_DEVICE, dst_device, C.c_void_p(int(dst_device_ptr))),
+              "gvec_gather_experience_records")
+        return None
 
     __del__ = close
 

@@ -24,6 +24,7 @@
  *     slot of max_width*max_height elements (padded batch, SURVEY config 5).
  *   - A handle is not thread-safe (mirrors Engine: externally serialised,
  *     internal/grpc/gameserver/game_manager.go:576-602).
+ *   - A handle lives on ONE device (gvec_create) or spans several (gvec_create_sharded).
  *   - There is NO CPU fallback behind this ABI: every compute entry point runs
  *     hand-written HIP kernels for gfx950 and fails with GVEC_E_NO_DEVICE when no
  *     GPU is present.
@@ -154,6 +155,30 @@ int32_t gvec_config_default(gvec_config* cfg);
 /* Replaces game.NewEngine for B engines (engine.go:62-71); boards arrive via gvec_reset. */
 int32_t gvec_create(const gvec_config* cfg, gvec_handle** out);
 int32_t gvec_destroy(gvec_handle* h);
+/* One handle over several GPUs ("device list ... one handle may span several GPUs").  The B = cfg->num_envs
+ * boards are split into num_devices contiguous shards whose sizes differ by at most one (shard i: base + (i < rem) envs
+ * from i*base + min(i, rem), base = B / n, rem = B % n); shard i lives on devices[i] for the whole run (cfg->device is
+ * ignored; a device may be listed more than once).  Boards are independent: no call moves board state between devices.
+ * Every entry point that takes GVEC_MEM_HOST buffers works on the sharded handle exactly as on a plain one - the
+ * caller's arrays are env-major over all B envs, every shard serves its slice, all devices at once - and the batch plays
+ * the same games whatever the number of shards (a shard's agent / auto-reset / map-generator draws are keyed by the
+ * env's index in the BATCH).  Entry points that take device pointers (GVEC_MEM_DEVICE, gvec_gym_*, gvec_export/import_
+ * records, gvec_device_buffer, gvec_set_stream, gvec_experience_records) act on one device: use them on the child handle
+ * gvec_shard returns (valid until the sharded handle is destroyed; never destroy it yourself).  Still not thread-safe:
+ * one caller at a time per sharded handle (internally one worker thread per shard). */
+int32_t gvec_create_sharded(const gvec_config* cfg, const int32_t* devices, int32_t num_devices, gvec_handle** out);
+int32_t gvec_num_shards(const gvec_handle* h);   /* 0 for a plain handle */
+int32_t gvec_shard(gvec_handle* h, int32_t i, gvec_handle** child, int32_t* env_begin, int32_t* num_envs, int32_t* device);
+/* The one exchange step of the path on a sharded handle: every shard writes the compact experience records
+ * (gvec_experience_records: needs gvec_experience_begin[_range] before the step) of ITS envs
+ * [shard_env_begin, shard_env_begin + n) - indices inside the shard, the same slice on every device - and ships them to one
+ * place: dst receives num_shards * n records, shard i's at record i * n; a record's env id is env_id_base + the env's
+ * index in the batch.  mem = GVEC_MEM_HOST: dst is host memory, each device copies its slab straight to it over its own
+ * PCIe link (what the Go StreamAggregator side, internal/grpc/gameserver/stream_aggregator.go:75-155, consumes);
+ * mem = GVEC_MEM_DEVICE: dst is device memory on dst_device, the slabs travel GPU-to-GPU (hipMemcpyPeerAsync: xGMI on an
+ * MI355X node) - for a learner that lives on a GPU.  Returns when every slab has landed. */
+int32_t gvec_gather_experience_records(gvec_handle* h, int32_t shard_env_begin, int32_t n, int32_t env_id_base, int32_t mem,
+                                       int32_t dst_device, void* dst);
 /* Work is enqueued on this hipStream_t (default: the null stream). */
 int32_t gvec_set_stream(gvec_handle* h, void* hip_stream);
 int32_t gvec_synchronize(gvec_handle* h);

@@ -62,3 +62,21 @@ def test_cpp_host_mirror_compiles():
         f.write('#include "generalsreinforcementlearning_amd/host/vec_engine.hpp"\nint main() { gvec::GameConfig c; (void)c; return 0; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I", ROOT, f.name])
     os.unlink(f.name)
+
+
+def test_sharded_create_fails_loudly_without_a_gpu():
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    import generalsreinforcementlearning_amd as g
+    from generalsreinforcementlearning_amd._lib import Config
+    L = g.load()
+    cfg = Config()
+    L.gvec_config_default(C.byref(cfg))
+    cfg.num_envs = 8
+    h = C.c_void_p()
+    devs = (C.c_int32 * 2)(0, 1)
+    assert L.gvec_create_sharded(C.byref(cfg), devs, 2, C.byref(h)) == -2 and not h.value   # GVEC_E_NO_DEVICE
+    assert b"no CPU fallback" in L.gvec_last_error()
