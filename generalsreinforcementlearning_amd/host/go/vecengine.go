@@ -8,13 +8,24 @@
 // (internal/game/engine.go:17-43); like Engine it is not goroutine-safe and is
 // meant to be driven under the caller's lock (game_manager.go:576-602).
 //
-// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.
-// Build with:  CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/generalsreinforcementlearning_amd -lgvec_hip" go build
+// WHERE THIS FILE GOES.  It imports .../internal/game/core (and vecengine_diff_test.go imports .../internal/game): Go
+// only lets packages INSIDE the reference module import its internal/ tree, so these files cannot be built from this
+// repository's directory.  Copy vecengine.go and vecengine_diff_test.go into the reference checkout as
+//
+//     <reference>/internal/game/vecengine/vecengine.go
+//     <reference>/internal/game/vecengine/vecengine_diff_test.go
+//
+// and point cgo at this repository (GVEC = its checkout; the .so must have been built: csrc/build.py):
+//
+//     export CGO_CFLAGS="-I$GVEC/include"
+//     export CGO_LDFLAGS="-L$GVEC/generalsreinforcementlearning_amd -lgvec_hip -Wl,-rpath,$GVEC/generalsreinforcementlearning_amd"
+//     cd <reference> && go test ./internal/game/vecengine/        # needs an MI355X: there is no CPU fallback
+//
+// There are deliberately no `#cgo CFLAGS/LDFLAGS` directives below: relative ${SRCDIR} paths would only be right for one
+// particular layout of the two checkouts.  NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.
 package vecengine
 
 /*
-#cgo CFLAGS:  -I${SRCDIR}/../../../include
-#cgo LDFLAGS: -L${SRCDIR}/../.. -lgvec_hip
 #include <stdlib.h>
 #include "generals_vec.h"
 */
@@ -37,6 +48,7 @@ var sentinels = map[int32]error{
 type Config struct {
 	NumEnvs, Width, Height, Players int
 	Device                          int
+	Devices                         []int // non-empty: ONE engine over several GPUs (gvec_create_sharded), Device ignored
 	FogOfWar                        bool // GameState.FogOfWarEnabled (engine_initializer.go:118: true)
 	AutoReset                       bool
 }
@@ -71,7 +83,16 @@ func NewVecEngine(cfg Config) (*VecEngine, error) {
 		c.auto_reset = 1
 	}
 	e := &VecEngine{cfg: cfg}
-	if err := apiErr(C.gvec_create(&c, &e.h), "gvec_create"); err != nil {
+	if len(cfg.Devices) > 0 {
+		// boards split into contiguous shards, one per listed device; every call below works unchanged on all B boards
+		devs := make([]C.int32_t, len(cfg.Devices))
+		for i, d := range cfg.Devices {
+			devs[i] = C.int32_t(d)
+		}
+		if err := apiErr(C.gvec_create_sharded(&c, &devs[0], C.int32_t(len(devs)), &e.h), "gvec_create_sharded"); err != nil {
+			return nil, err
+		}
+	} else if err := apiErr(C.gvec_create(&c, &e.h), "gvec_create"); err != nil {
 		return nil, err
 	}
 	e.stride = int(C.gvec_tile_stride(e.h))
@@ -233,4 +254,18 @@ func (e *VecEngine) ComputePlayerVisibility(playerID int) (visible, fog []uint8,
 	fog = make([]uint8, e.cfg.NumEnvs*e.stride)
 	rc := C.gvec_player_visibility(e.h, C.int32_t(playerID), (*C.uint8_t)(unsafe.Pointer(&visible[0])), (*C.uint8_t)(unsafe.Pointer(&fog[0])), C.GVEC_MEM_HOST)
 	return visible, fog, apiErr(rc, "gvec_player_visibility")
+}
+
+// GatherExperienceRecords is the sharded engine's hand-off to the process that feeds StreamAggregator
+// (internal/grpc/gameserver/stream_aggregator.go:75-155): after ExperienceBegin() + Step(), every GPU writes the compact
+// experience records of its envs [shardEnvBegin, shardEnvBegin+n) and copies them into one host slab over its own PCIe
+// link.  Record layout: include/generals_vec.h "experience records"; expand with the rules of experience.py decode_records.
+func (e *VecEngine) ExperienceBegin() error { return apiErr(C.gvec_experience_begin(e.h), "gvec_experience_begin") }
+
+func (e *VecEngine) GatherExperienceRecords(shardEnvBegin, n, envIDBase int) ([]byte, error) {
+	shards := int(C.gvec_num_shards(e.h))
+	rec := int(C.gvec_experience_record_bytes(e.h))
+	out := make([]byte, shards*n*rec)
+	rc := C.gvec_gather_experience_records(e.h, C.int32_t(shardEnvBegin), C.int32_t(n), C.int32_t(envIDBase), C.GVEC_MEM_HOST, 0, unsafe.Pointer(&out[0]))
+	return out, apiErr(rc, "gvec_gather_experience_records")
 }

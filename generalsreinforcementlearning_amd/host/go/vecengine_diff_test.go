@@ -1,6 +1,9 @@
 // Differential test against the real Go engine, for hosts that have both a Go toolchain and an
 // MI355X: steps B reference engines (internal/game) and one VecEngine with identical boards and
 // actions and compares every tile after every turn.  Not run in this repository's CI (no Go here).
+// Lives next to vecengine.go INSIDE the reference module (<reference>/internal/game/vecengine/): it imports the
+// reference's internal packages, which Go forbids from any other module - see vecengine.go's header for the
+// destination and the CGO_CFLAGS / CGO_LDFLAGS to export.
 package vecengine
 
 import (
