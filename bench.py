@@ -61,6 +61,32 @@ def kernel_source_hash():
     return hh.hexdigest()[:16]
 
 
+def step_kernel_isa_hash(w=20, h=20, p=4):
+    """sha256 of the step kernel's generated gfx950 instructions (csrc/build/*.s, kept by the build): unlike the source
+    hash it survives edits that do not touch this kernel's code (the C ABI file, other kernels, comments).  None when the
+    build's ISA listing is not there."""
+    import re
+    path = os.path.join(ROOT, "generalsreinforcementlearning_amd", "csrc", "build", "gvec_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(path):
+        return None
+    maxp = next(m for m in (2, 4, 8) if m >= p)
+    nslot = next(n for n in (1, 2, 4, 7, 10, 16) if n * 64 >= w * h)
+    odd = 1 if w * h <= 32 * (2 * nslot - 1) else 0
+    sym = f"_ZN4gvec11step_kernelILi{maxp}ELi{nslot}ELb1ELb{odd}EEEvNS_8StepArgsE"
+    hh, inside = hashlib.sha256(), False
+    for line in open(path):
+        if line.startswith(sym + ":"):
+            inside = True
+            continue
+        if inside:
+            if line.startswith(".Lfunc_end"):
+                break
+            t = line.split(";")[0].strip()
+            if t and not t.startswith((".", "//")) and not re.match(r"^\.?L[A-Za-z_0-9]*:$", t):
+                hh.update(re.sub(r"\.LBB\d+_", ".LBB_", t).encode() + b"\n")   # block labels carry the function's index in the file
+    return hh.hexdigest()[:16] if inside else None
+
+
 def go_probe():
     """The Go engine itself can only be timed where a Go toolchain AND the reference module exist
     (bench/go/step_bench_test.go; GRL_REFERENCE_DIR = a checkout of the reference).  Probed, never assumed."""
@@ -478,7 +504,9 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("envs") == B and rec.get("board") == [W, H, P] and rec.get("kernel_source_hash") == kernel_source_hash():
+                isa = step_kernel_isa_hash(W, H, P)
+                same_build = rec.get("kernel_source_hash") == kernel_source_hash() or (isa is not None and rec.get("step_kernel_isa_hash") == isa)
+                if rec.get("envs") == B and rec.get("board") == [W, H, P] and same_build:
                     traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None

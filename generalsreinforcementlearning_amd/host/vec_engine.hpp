@@ -34,6 +34,7 @@ struct GameConfig {
   int NumEnvs = 1, Width = 20, Height = 20, Players = 2, Device = 0;
   bool FogOfWarEnabled = true;  // engine_initializer.go:118
   bool AutoReset = false;
+  std::vector<int32_t> Devices;  // non-empty: one engine over several GPUs (gvec_create_sharded; Device is then ignored)
 };
 
 struct GameState {  // state.go:25-34 + Player (state.go:7-13), env-major planes
@@ -54,7 +55,8 @@ class VecEngine {
     c.device = cfg.Device;
     c.fog_of_war = cfg.FogOfWarEnabled ? 1 : 0;
     c.auto_reset = cfg.AutoReset ? 1 : 0;
-    check(gvec_create(&c, &h_), "gvec_create");
+    if (!cfg.Devices.empty()) check(gvec_create_sharded(&c, cfg.Devices.data(), static_cast<int32_t>(cfg.Devices.size()), &h_), "gvec_create_sharded");
+    else check(gvec_create(&c, &h_), "gvec_create");
     stride_ = gvec_tile_stride(h_);
     mask_bytes_ = gvec_mask_bytes(h_);
     actions_.resize(static_cast<size_t>(cfg.NumEnvs) * cfg.Players);
@@ -68,6 +70,7 @@ class VecEngine {
   VecEngine& operator=(const VecEngine&) = delete;
 
   int TileStride() const { return stride_; }
+  gvec_handle* Handle() const { return h_; }  // for the entry points this mirror does not wrap
 
   // boards: [n][stride] planes, tile index y*W+x (core/board.go:108); runs performInitialSetup
   void Reset(const std::vector<int32_t>& army, const std::vector<int8_t>& owner, const std::vector<uint8_t>& type,

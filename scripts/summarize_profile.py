@@ -64,9 +64,9 @@ json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 if "hbm_bytes_per_launch" in out and waves:
     b = out.get("bench_line_under_profiler", {}).get("config", {})
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import kernel_source_hash
+    from bench import kernel_source_hash, step_kernel_isa_hash
     json.dump({"envs": int(waves), "board": b.get("board", [20, 20, 4]), "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
-               "kernel_source_hash": kernel_source_hash(),
+               "kernel_source_hash": kernel_source_hash(), "step_kernel_isa_hash": step_kernel_isa_hash(*b.get("board", [20, 20, 4])),
                "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"},
               open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -149,8 +149,31 @@ void legal_action_mask() {
 }
 }  // namespace
 
+// the same basic turn on a sharded engine (gvec_create_sharded: 5 envs over two shards, both on device 0 here)
+void sharded_engine_basic_turn() {
+  gvec::GameConfig c = cfg(5, 5, 1);
+  c.NumEnvs = 5;
+  c.Devices = {0, 0};
+  gvec::VecEngine e(c);
+  EXPECT(gvec_num_shards(e.Handle()) == 2);
+  const Board b(5, 5, 1, {{2, 2, 0, 2, General}, {4, 0, -1, 40, City}});
+  std::vector<int32_t> army, w(5, 5), h(5, 5), p(5, 1);
+  std::vector<int8_t> owner;
+  std::vector<uint8_t> type;
+  for (int i = 0; i < 5; ++i) {
+    army.insert(army.end(), b.army.begin(), b.army.end());
+    owner.insert(owner.end(), b.owner.begin(), b.owner.end());
+    type.insert(type.end(), b.type.begin(), b.type.end());
+  }
+  e.Reset(army, owner, type, w, h, p);
+  const std::vector<int32_t>& err = e.Step({{}, {}, {}, {}, {}});
+  gvec::GameState s = e.GetGameState(0, 5);
+  for (int i = 0; i < 5; ++i) EXPECT(err[i] == 0 && s.Turn[i] == 1 && s.ArmyCount[i] == 3 && !s.GameOver[i]);
+}
+
 int main() {
   try {
+    sharded_engine_basic_turn();
     step_basic_turn();
     step_game_over_returns_error();
     production_turn_25_vs_24();

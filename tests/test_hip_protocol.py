@@ -6,8 +6,9 @@ with its own agent and pool (same counter RNG, keyed by env id):
   configs[1]  4,096 x 10x10 2P fog-off   ALL envs compared with the oracle after EVERY turn
   configs[2]  65,536 x 15x15 2P fog-on   a 4,096-env subset compared after EVERY turn (+ its legal masks every 25 turns),
                                          then every env of a fused 500-turn rollout == the per-turn rollout
-  configs[3]  262,144 x 20x20 4P fog-on  (the 8-GPU configuration's workload on one GPU) the subset every 25 turns; seed 1
-                                         also checks fused == per-turn over all 262,144 envs
+  configs[3]  262,144 x 20x20 4P fog-on  (the 8-GPU configuration's workload on one GPU) the subset after EVERY turn for seed 1
+                                         and every 5 turns for seeds 2, 3 (SURVEY asks every 25); seed 1 also checks
+                                         fused == per-turn over all 262,144 envs
 
 "Compared" = H.assert_states_equal: every tile plane (army, owner, type, visible, listed, changed, vis_changed), turn,
 done, winner, sizes, alive / army_count / tile_count per player, general_idx by contract.  All through the C ABI."""
@@ -93,10 +94,10 @@ def test_config2_65536x15x15_subset_every_turn_then_all_envs_fused(g, seed):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
-def test_config3_262144x20x20_4p_subset_every_25_turns(g, seed):
+def test_config3_262144x20x20_4p_subset_every_turn_or_5(g, seed):
     B, sub, w, h, p = 262144, 4096, 20, 20, 4
     eng, ora = _pair(g, B, sub, w, h, p, True, seed, pool=4096)
-    _lockstep(eng, ora, sub, seed, permille=5, every=25, mask_every=0, ctx="configs[3]")
+    _lockstep(eng, ora, sub, seed, permille=5, every=(1 if seed == 1 else 5), mask_every=0, ctx="configs[3]")
     # the masks of the subset once: gvec_legal_mask into a device tensor, only the subset crosses PCIe (all of it is 218 MB)
     import torch
     from generalsreinforcementlearning_amd._lib import check
