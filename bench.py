@@ -132,24 +132,27 @@ def cpu_baseline(w, h, p, fog, seed, budget_s=15.0):
     ora = O.OracleBatch(envs, w, h, p, fog=fog)
     ora.reset(army, owner, typ, ws, hs, ps)
     ora.set_pool(1024, seed + 17)
+    # the same work per env-step as the GPU leg: agent sampling from the legal mask, Engine.Step, then the players' legal
+    # masks packed (what the step kernel emits every turn)
+    bits = np.zeros((envs, p, ora.mask_bytes), np.uint8)
     # calibrate, then run ~budget_s of work
     t0 = time.perf_counter()
-    s0 = ora.rollout(4, seed, 0, threads=cores)
+    s0 = ora.rollout(4, seed, 0, threads=cores, legal_bits=bits)
     dt = max(time.perf_counter() - t0, 1e-6)
     turns = int(max(8, min(20000, budget_s / (dt / 4))))
     t0 = time.perf_counter()
-    steps = ora.rollout(turns, seed, 0, threads=cores)
+    steps = ora.rollout(turns, seed, 0, threads=cores, legal_bits=bits)
     dt = time.perf_counter() - t0
     one = O.OracleBatch(256, w, h, p, fog=fog)
     one.reset(army[:256], owner[:256], typ[:256], ws[:256], hs[:256], ps[:256])
     t1 = time.perf_counter()
-    s1 = one.rollout(max(8, turns // 8), seed, 0, threads=1)
+    s1 = one.rollout(max(8, turns // 8), seed, 0, threads=1, legal_bits=bits[:256])
     d1 = time.perf_counter() - t1
     del s0
     return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_thread_value": s1 / d1,
             "sample": f"{envs} boards {w}x{h} P{p} fog={'on' if fog else 'off'} x {turns} turns, oracle random agent + "
-                      f"Engine.Step restatement (no mask packing), OpenMP over boards; {dt:.1f} s of CPU work",
+                      f"Engine.Step restatement + packed legal masks every turn (the GPU leg's work), OpenMP over boards; {dt:.1f} s of CPU work",
             "note": "C restatement of the Go engine (oracle/generals_oracle.c), never the Go engine itself",
             "go_reference": go_probe()}
 

@@ -1123,6 +1123,13 @@ static void redeal_env(ora_batch* b, int id) {
 }
 
 int64_t ora_batch_rollout(ora_batch* b, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t threads) {
+  return ora_batch_rollout_masks(b, turns, seed, invalid_permille, threads, NULL);
+}
+
+/* The same rollout; legal_bits != NULL: after every turn an env also packs its players' legal masks into its slot of
+ * legal_bits [B][max_p][mask_bytes], like gvec_step / per-turn gvec_rollout do on the device - the work the timed CPU
+ * baseline must include to be the same workload as the GPU leg (bench.py). */
+int64_t ora_batch_rollout_masks(ora_batch* b, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t threads, uint8_t* legal_bits) {
   int64_t steps = 0;
   (void)threads;
 #ifdef _OPENMP
@@ -1140,6 +1147,7 @@ int64_t ora_batch_rollout(ora_batch* b, int32_t turns, uint64_t seed, int32_t in
       }
       agent_env(b, b->env[id], ek, invalid_permille, acts, scratch);
       step_env(b, id, acts);
+      if (legal_bits) pack_legal_bits(b, b->env[id], legal_bits + (size_t)id * (size_t)b->max_p * (size_t)b->mask_bytes, scratch);
       steps++;
     }
     free(scratch);

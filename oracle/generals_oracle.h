@@ -188,6 +188,8 @@ int32_t    ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t 
 int32_t    ora_batch_set_pool(ora_batch* b, int32_t pool_size, uint64_t seed, const int32_t* w, const int32_t* h, const int32_t* p);
 /* K turns of agent+step for every env; returns env-steps advanced. */
 int64_t    ora_batch_rollout(ora_batch* b, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t threads);
+int64_t    ora_batch_rollout_masks(ora_batch* b, int32_t turns, uint64_t seed, int32_t invalid_permille, int32_t threads,
+                                   uint8_t* legal_bits /*[B][max_p][mask_bytes] or NULL*/);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,8 @@ def lib():
     L.ora_batch_set_pool.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, i32p, i32p, i32p]
     L.ora_batch_rollout.restype = C.c_int64
     L.ora_batch_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
+    L.ora_batch_rollout_masks.restype = C.c_int64
+    L.ora_batch_rollout_masks.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, u8p]
     L.ora_batch_next_fog_legacy.argtypes = [C.c_void_p, u8p, u8p]
     L.ora_engine_clone.restype = C.c_void_p
     L.ora_engine_clone.argtypes = [C.c_void_p]
@@ -380,8 +382,13 @@ class OracleBatch:
         w, h, p = cv(w), cv(h), cv(p)
         self.L.ora_batch_set_pool(self.b, pool_size, seed, _ptr(w, i32p), _ptr(h, i32p), _ptr(p, i32p))
 
-    def rollout(self, turns, seed, invalid_permille=0, threads=1):
-        return self.L.ora_batch_rollout(self.b, turns, seed, invalid_permille, threads)
+    def rollout(self, turns, seed, invalid_permille=0, threads=1, legal_bits=None):
+        """legal_bits: a uint8 [B][max_p][mask_bytes] array -> every env also packs its legal masks after every turn
+        (the device's per-turn mask emission: the same work for the timed CPU baseline)."""
+        if legal_bits is None:
+            return self.L.ora_batch_rollout(self.b, turns, seed, invalid_permille, threads)
+        assert legal_bits.dtype == np.uint8 and legal_bits.size == self.B * self.max_p * self.mask_bytes and legal_bits.flags.c_contiguous
+        return self.L.ora_batch_rollout_masks(self.b, turns, seed, invalid_permille, threads, legal_bits.ctypes.data_as(u8p))
 
     def engine(self, env):
         e = self.L.ora_batch_engine(self.b, env)

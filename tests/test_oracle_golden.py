@@ -356,3 +356,18 @@ def test_oracle_is_clean_under_sanitizers():
         pytest.skip("no gcc")
     r = subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "-s", "sanitize"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sanitizer run OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rollout_with_mask_packing_plays_the_same_games():
+    """bench.py's CPU baseline packs the legal masks after every turn (the GPU leg's work): the games are the same, and the
+    masks it leaves are the state's."""
+    import _harness as H
+    B = 48
+    army, owner, typ, ws, hs, ps = H.gen_boards(1, [(20, 20, 4)] * B, 20, 20)
+    a, b = O.OracleBatch(B, 20, 20, 4), O.OracleBatch(B, 20, 20, 4)
+    for x in (a, b):
+        x.reset(army, owner, typ, ws, hs, ps)
+    bits = np.zeros((B, 4, a.mask_bytes), np.uint8)
+    assert a.rollout(40, 3, 5) == b.rollout(40, 3, 5, legal_bits=bits)
+    sa, sb = a.read_state(), b.read_state()
+    assert all(np.array_equal(sa[f], sb[f]) for f in sa) and np.array_equal(bits, a.legal_mask())
