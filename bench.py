@@ -345,6 +345,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
+        # librccl writes a five-line banner (versions, hostname, library path) to STDOUT when its first communicator comes
+        # up: stdout carries rank 0's ONE JSON line and nothing else, so file descriptor 1 points at stderr until RCCL is up
+        sys.stdout.flush()
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
         if os.environ.get("GVEC_BENCH_DIST_INIT") == "gloo":
             dist.init_process_group("gloo")   # diagnostics only (scripts/rccl_tax.sh)
         else:
@@ -356,6 +361,9 @@ def main():
         # clock-settle phase; the bracketing barriers are then ~20 us collectives.
         dist.barrier()
         torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
