@@ -69,6 +69,7 @@ SYMBOLS = {
     "gvec_experience_record_bytes": (_i32, [_vp]),
     "gvec_experience_records": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gvec_record_agent_actions": (_i32, [_vp, _i32]),
+    "gvec_expand_experience_records": (_i32, [_i32, _vp, C.POINTER(C.c_int32), _vp, _i32, _vp, _vp, _vp, _vp]),
     "gvec_gym_observe": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gvec_gym_finish_step": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvec_gym_actions": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1258,6 +1258,22 @@ int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int3
   return GVEC_OK;
 }
 
+int32_t gvec_expand_experience_records(int32_t device, void* hip_stream, const int32_t* layout8, const void* records, int32_t n, float* state,
+                                       float* next_state, uint8_t* action_mask, int32_t* meta) {
+  if (!layout8 || !records || !state || !next_state || !action_mask || !meta || n < 0) return GVEC_E_INVALID;
+  const int rd = layout8[0], mp = layout8[1], fd = layout8[2], ns = layout8[3], stride = layout8[5];
+  if (mp < 1 || mp > GVEC_MAX_PLAYERS || fd < 1 || fd > 32 || ns < 1 || ns > 16 || stride < 1 || stride > GVEC_MAX_DIM * GVEC_MAX_DIM ||
+      stride > 32 * fd || stride > 64 * ns || rd < 4 + 2 * mp + (8 * mp + 3) * fd + ns * 64) {
+    set_err("gvec_expand_experience_records: layout {%d, %d, %d, %d, ., %d} is not one gvec_experience_record_layout produces", rd, mp, fd, ns, stride);
+    return GVEC_E_INVALID;
+  }
+  if (n == 0) return GVEC_OK;
+  RET_IF(ensure_device());
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(launch_expand_records(records, n, layout8, state, next_state, action_mask, meta, reinterpret_cast<hipStream_t>(hip_stream)));
+  return GVEC_OK;
+}
+
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
   if (!h) return GVEC_E_INVALID;
   if (h->sharded()) {

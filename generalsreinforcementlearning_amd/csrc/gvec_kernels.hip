@@ -586,6 +586,110 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void experience_record_kernel
   for (int k = R.army_next() + NSLOT * 32 + lane; k < A.record_dw; k += 64) rec[k] = 0u;
 }
 
+// The consumer side of the exchange step: expands compact experience records - on whatever GPU they were
+// gathered to - into what SimpleCollector.OnStateTransition (collector.go:41-75) puts into every acting player's
+// experiencepb.Experience: StateToTensor(prevState, p), StateToTensor(currState, p) ([9][H][W] float32, serializer.go:37-109),
+// GenerateActionMask(prevState, p) ([]bool, index t*4 + d, d = 0 up, 1 down, 2 left, 3 right, :112-176), and the scalar
+// fields.  One wavefront per record; needs no engine handle (the record carries its own W, H, P, flags; the layout
+// constants arrive as arguments).  A u16 army saturated at 65,535 is exact here: the tensor clamps army / 1000 at 1.
+struct ExpandArgs {
+  const uint32_t* records;  // [n][record_dw]
+  float* state;             // [n][mp][9*stride]
+  float* next_state;        // [n][mp][9*stride]
+  uint8_t* mask;            // [n][mp][4*stride] 0/1 bytes
+  int32_t* meta;            // [n][mp][8]: present (valid record & the player acted), env id, player, turn, action, reward bits, done, W | H << 8
+  int32_t n, record_dw, mp, fd, ns, stride;
+};
+
+__device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own, const uint32_t* vis, const uint32_t* types, const uint16_t* army,
+                                              int p, int P, int mp, int fd, int N, int stride, bool fog) {
+  const int lane = lane_id();
+  for (int t0 = 0; t0 < stride; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < N) {
+      const int dwi = t >> 5;
+      const uint32_t bit = 1u << (t & 31);
+      bool owned = false;
+      for (int q = 0; q < P; ++q) owned |= (own[q * fd + dwi] & bit) != 0u;
+      const bool mine = (own[p * fd + dwi] & bit) != 0u;
+      const bool seen = (vis[p * fd + dwi] & bit) != 0u;
+      const bool spec = ((types[0 * fd + dwi] | types[1 * fd + dwi]) & bit) != 0u, mount = (types[2 * fd + dwi] & bit) != 0u;
+      const bool visible = !fog || seen;      // :50
+      const bool open = visible && !mount;    // mountains short-circuit (:68-71)
+      const int a = (int)army[t];
+      float norm = (float)a / 1000.0f;        // :82-85
+      norm = norm > 1.0f ? 1.0f : norm;
+      const float arm = (a > 0) ? norm : 0.0f;
+      const size_t n = (size_t)N;
+      st_stream<GVEC_NT_MASK>(out + 0 * n + t, (open && mine) ? arm : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 1 * n + t, (open && !mine && owned) ? arm : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 2 * n + t, (open && mine) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 3 * n + t, (open && !mine && owned) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 4 * n + t, (open && !owned) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 5 * n + t, (open && spec) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 6 * n + t, (visible && mount) ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 7 * n + t, visible ? 1.0f : 0.0f);
+      st_stream<GVEC_NT_MASK>(out + 8 * n + t, visible ? 0.0f : 1.0f);
+    }
+  }
+  for (int i = 9 * N + lane; i < 9 * stride; i += 64) out[i] = 0.0f;  // a smaller board in a padded batch: clear the rest of the slot
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void expand_records_kernel(ExpandArgs A) {
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (i >= A.n) return;
+  const uint32_t* rec = A.records + (size_t)i * A.record_dw;
+  const int mp = A.mp, fd = A.fd;
+  const uint32_t r1 = rec[1];
+  int W = (int)(r1 & 0xFFu), H = (int)((r1 >> 8) & 0xFFu), P = (int)((r1 >> 16) & 0xFFu);
+  const uint32_t flags = r1 >> 24;
+  const bool ok = W >= 1 && H >= 1 && W * H <= A.stride && P >= 1 && P <= mp;   // a malformed record expands to nothing
+  if (!ok) W = H = P = 0;
+  const int N = W * H;
+  const uint32_t acted = ok && (flags & 4u) ? rec[2] : 0u;   // a void record (re-dealt env) yields no experience
+  const int off_planes = 4 + 2 * mp, off_mask = off_planes + (4 * mp + 3) * fd, off_prev = off_mask + 4 * mp * fd, off_next = off_prev + A.ns * 32;
+  const uint32_t* prev_own = rec + off_planes;
+  const uint32_t* prev_vis = prev_own + mp * fd;
+  const uint32_t* next_own = prev_vis + mp * fd;
+  const uint32_t* next_vis = next_own + mp * fd;
+  const uint32_t* types = next_vis + mp * fd;   // general, city, mountain
+  const uint16_t* army_prev = reinterpret_cast<const uint16_t*>(rec + off_prev);
+  const uint16_t* army_next = reinterpret_cast<const uint16_t*>(rec + off_next);
+  for (int p = 0; p < mp; ++p) {
+    const size_t slot = (size_t)i * mp + p;
+    const bool present = p < P && ((acted >> p) & 1u) != 0u;
+    int32_t* meta = A.meta + slot * 8;
+    if (lane < 8) {
+      int32_t v = 0;
+      v = (lane == 0) ? (present ? 1 : 0) : v;
+      v = (lane == 1) ? (int32_t)rec[3] : v;
+      v = (lane == 2) ? p : v;
+      v = (lane == 3) ? (int32_t)rec[0] : v;
+      v = (lane == 4) ? (int32_t)rec[4 + p] : v;
+      v = (lane == 5) ? (int32_t)rec[4 + mp + p] : v;
+      v = (lane == 6) ? (int32_t)(flags & 1u) : v;
+      v = (lane == 7) ? (int32_t)((uint32_t)W | ((uint32_t)H << 8)) : v;
+      meta[lane] = present ? v : ((lane == 2) ? p : 0);
+    }
+    float* st = A.state + slot * 9 * (size_t)A.stride;
+    float* nx = A.next_state + slot * 9 * (size_t)A.stride;
+    uint8_t* mk = A.mask + slot * 4 * (size_t)A.stride;
+    if (!present) {  // wave-uniform
+      for (int k = lane; k < 9 * A.stride; k += 64) st[k] = nx[k] = 0.0f;
+      for (int k = lane; k < 4 * A.stride; k += 64) mk[k] = 0;
+      continue;
+    }
+    expand_tensor(st, prev_own, prev_vis, types, army_prev, p, P, mp, fd, N, A.stride, (flags & 2u) != 0u);
+    expand_tensor(nx, next_own, next_vis, types, army_next, p, P, mp, fd, N, A.stride, (flags & 2u) != 0u);
+    const uint32_t* m = rec + off_mask + p * 4 * fd;   // [d][fd]
+    for (int k = lane; k < 4 * A.stride; k += 64) {
+      const int t = k >> 2, d = k & 3;
+      mk[k] = (uint8_t)((t < N) ? ((m[d * fd + (t >> 5)] >> (t & 31)) & 1u) : 0u);
+    }
+  }
+}
+
 // Serializer.StateToTensor (internal/experience/serializer.go:37-109): [9][H][W] float32 from one
 // player's perspective; the output is 9 coalesced channel planes per 64-tile slot.
 template <int MAXP, int NSLOT>
@@ -1585,6 +1689,23 @@ hipError_t launch_gym_step(const Variant& v, const StepArgs& in, const GymStepAr
 }
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gym_actions_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* layout8, float* state, float* next_state, uint8_t* mask,
+                                 int32_t* meta, hipStream_t s) {
+  ExpandArgs a;
+  a.records = reinterpret_cast<const uint32_t*>(records);
+  a.state = state;
+  a.next_state = next_state;
+  a.mask = mask;
+  a.meta = meta;
+  a.n = n;
+  a.record_dw = layout8[0];
+  a.mp = layout8[1];
+  a.fd = layout8[2];
+  a.ns = layout8[3];
+  a.stride = layout8[5];
+  hipLaunchKernelGGL(expand_records_kernel, wave_grid(n), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {

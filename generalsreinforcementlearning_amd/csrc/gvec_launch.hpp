@@ -183,6 +183,9 @@ struct GymStepArgs {
   int32_t* prev_stats;         // [B][3*MAXP], as GymArgs
   int32_t stride, player, max_turns;
 };
+// the consumer side of the record exchange: layout8 as gvec_experience_record_layout fills it
+hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* layout8, float* state, float* next_state, uint8_t* mask,
+                                 int32_t* meta, hipStream_t s);
 hipError_t launch_gym_step(const Variant& v, const StepArgs& a, const GymStepArgs& g, hipStream_t s);
 hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s);
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s);

@@ -136,6 +136,40 @@ def decode_records(slab, layout, drop_invalid=True):
     return res
 
 
+def expand_records_device(records, layout, stream=None):
+    """decode_records on the GPU (gvec_expand_experience_records): `records` a CUDA uint8 / int32 tensor holding k records
+    back to back, e.g. what RecordGather / gvec_gather_experience_records delivered.  Returns the same batch dict as
+    decode_records - torch tensors on the records' device, one entry per (record, player) that acted, record-major:
+    state / next_state float32 [K, 9 * stride] (an experience's own [9, H, W] at the start of its row), action_mask bool
+    [K, 4 * stride], env, player_id, turn, action, reward (float32), done, width, height.  The expansion runs at HBM speed
+    (28.8 KB per experience at 20x20); decode_records' per-record numpy loop is the readable twin the tests compare it with."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    L = _lib.load()
+    rd, mp, stride = layout["record_dw"], layout["mp"], layout["stride"]
+    flat = records.contiguous().view(torch.uint8).reshape(-1)
+    n = flat.numel() // (rd * 4)
+    dev = flat.device
+    lay = (C.c_int32 * 8)(rd, mp, layout["fd"], layout["ns"], layout["max_players"], stride, 0, 0)
+    state = torch.empty((n * mp, 9 * stride), dtype=torch.float32, device=dev)
+    nxt = torch.empty_like(state)
+    mask = torch.empty((n * mp, 4 * stride), dtype=torch.uint8, device=dev)
+    meta = torch.empty((n * mp, 8), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _lib.check(L.gvec_expand_experience_records(dev.index or 0, C.c_void_p(int(s)), lay, C.c_void_p(flat.data_ptr()), n, C.c_void_p(state.data_ptr()),
+                                                C.c_void_p(nxt.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(meta.data_ptr())),
+               "gvec_expand_experience_records")
+    keep = torch.nonzero(meta[:, 0] != 0).reshape(-1)
+    m = meta[keep]
+    return {"env": m[:, 1].to(torch.int64), "player_id": m[:, 2], "turn": m[:, 3], "action": m[:, 4],
+            "reward": m[:, 5].contiguous().view(torch.float32), "done": m[:, 6] != 0, "width": (m[:, 7] & 0xFF).to(torch.int64),
+            "height": ((m[:, 7] >> 8) & 0xFF).to(torch.int64), "state": state[keep], "next_state": nxt[keep],
+            "action_mask": mask[keep].view(torch.bool)}
+
+
 class ExperienceBatcher:
     """BatchProcessor (internal/grpc/gameserver/batch_processor.go:12-166) as StreamAggregator configures it
     (stream_aggregator.go:64-69: 32 experiences or 100 ms, whichever comes first): add() returns the batches that

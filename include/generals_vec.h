@@ -333,6 +333,20 @@ int32_t gvec_experience_record_layout(gvec_handle* h, int32_t* out8);
 int32_t gvec_experience_record_bytes(gvec_handle* h);
 int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int32_t mem, int32_t env_begin,
                                 int32_t n, int32_t env_id_base, void* dst_device);
+/* The CONSUMER side of the exchange (the GPU the records were gathered to, e.g. rank 0 feeding StreamAggregator or a
+ * learner): expands n compact records (device memory on `device`) into the fields of the experiencepb.Experience messages
+ * SimpleCollector.OnStateTransition builds (collector.go:41-75), one slot per (record, player), [n][MP] record-major,
+ * MP = layout8[1] (layout8 as gvec_experience_record_layout fills it - the sender's; no engine handle is needed here):
+ *   state, next_state  float32 [n][MP][9 * stride]: StateToTensor(prevState / currState, p), index c*H*W + y*W + x with
+ *                      the record's own W, H at the start of the slot (stride = layout8[5]);
+ *   action_mask        uint8   [n][MP][4 * stride]: GenerateActionMask(prevState, p) as 0/1 bytes, index t*4 + d,
+ *                      d = 0 up, 1 down, 2 left, 3 right (the []bool of serializer.go:112-176);
+ *   meta               int32   [n][MP][8]: present (1: the record is valid and player p acted - only then the slot
+ *                      holds an experience, else it is zeroed), env id, player id, currState.Turn, action index, reward
+ *                      (float32 bits), done, W | H << 8.
+ * Enqueued on hip_stream (may be NULL) of `device`; device pointers only.  experience.py: expand_records_device. */
+int32_t gvec_expand_experience_records(int32_t device, void* hip_stream, const int32_t* layout8, const void* records, int32_t n,
+                                       float* state, float* next_state, uint8_t* action_mask, int32_t* meta);
 /* on != 0: per-turn rollouts (gvec_rollout fused = 0) store the agent's moves in the handle's action buffer. */
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on);
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);

@@ -276,7 +276,7 @@ def test_experience_records_match_oracle_encoding_and_collector(g, sizes, auto_r
     form expands to exactly what SimpleCollector.OnStateTransition would have put on the wire."""
     import torch
     import _records as R
-    from generalsreinforcementlearning_amd.experience import VecExperienceCollector, decode_records
+    from generalsreinforcementlearning_amd.experience import VecExperienceCollector, decode_records, expand_records_device
     B = 36
     per_env = [sizes[i % len(sizes)] for i in range(B)]
     mw, mh, mp = max(s[0] for s in per_env), max(s[1] for s in per_env), max(s[2] for s in per_env)
@@ -318,6 +318,18 @@ def test_experience_records_match_oracle_encoding_and_collector(g, sizes, auto_r
                 for f in ("state", "next_state"):
                     assert np.array_equal(np.asarray(dec[f][i]).view(np.uint32), np.asarray(batch[f][i]).view(np.uint32)), (k, i, f)
                 assert np.array_equal(dec["action_mask"][i], batch["action_mask"][i])
+            # the GPU-side consumer (gvec_expand_experience_records) expands the same slab to the same experiences
+            ex = expand_records_device(slab, lay)
+            assert len(ex["env"]) == len(dec["env"])
+            for f in ("env", "player_id", "turn", "action", "done", "width", "height"):
+                assert np.array_equal(ex[f].cpu().numpy(), np.asarray(dec[f])), (k, f)
+            assert np.array_equal(ex["reward"].cpu().numpy().view(np.uint32), dec["reward"].view(np.uint32))
+            xs, xn, xm = ex["state"].cpu().numpy(), ex["next_state"].cpu().numpy(), ex["action_mask"].cpu().numpy()
+            for i in range(len(dec["env"])):
+                hw = int(dec["width"][i]) * int(dec["height"][i])
+                for got, want in ((xs[i], dec["state"][i]), (xn[i], dec["next_state"][i])):
+                    assert np.array_equal(got[: 9 * hw].view(np.uint32), np.asarray(want).reshape(-1).view(np.uint32)) and not got[9 * hw:].any(), (k, i)
+                assert np.array_equal(xm[i][: 4 * hw], dec["action_mask"][i]) and not xm[i][4 * hw:].any()
             n += len(dec["env"])
     assert n > 200 and (invalid > 0) == auto_reset
     # a range of envs, the device agent's own actions
@@ -332,3 +344,21 @@ def test_experience_records_match_oracle_encoding_and_collector(g, sizes, auto_r
     eng.synchronize()
     got = slab.cpu().numpy().view(np.uint32).reshape(B, lay["record_dw"])[:16]
     assert np.array_equal(got, R.encode(ora, snap, oacts, lay, envs=range(8, 24)))
+
+
+@pytest.mark.gpu
+def test_expand_records_rejects_what_is_not_a_layout_and_ignores_malformed_records(g):
+    import ctypes as C
+    import torch
+    from generalsreinforcementlearning_amd.experience import expand_records_device
+    eng = g.VecEngine(8, 10, 10, 2)
+    lay = eng.experience_record_layout()
+    bad = dict(lay, record_dw=lay["record_dw"] - 40)
+    with pytest.raises(g.GvecError):
+        expand_records_device(torch.zeros(8 * bad["record_dw"], dtype=torch.int32, device="cuda"), bad)
+    # records whose header claims a board beyond the layout, or more players than slots: no experience, no out-of-bounds access
+    junk = torch.zeros((8, lay["record_dw"]), dtype=torch.int32, device="cuda")
+    junk[:, 1] = (200 | (200 << 8) | (7 << 16) | (4 << 24))
+    junk[:, 2] = 0xFF
+    ex = expand_records_device(junk, lay)
+    assert len(ex["env"]) == 0
