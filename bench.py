@@ -335,6 +335,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # diagnostics for a ONE-GPU box (never a result: the line says "rehearsal_same_device"): GVEC_BENCH_SAME_DEVICE=1 lets the N
+    # ranks share device 0 - RCCL refuses two ranks on one GPU, so gloo carries the control traffic and the record slabs
+    # go through host memory - to run the whole N > 1 choreography (own ranks, real engines, record kernels, decode)
+    same_dev = os.environ.get("GVEC_BENCH_SAME_DEVICE") == "1"
+    if same_dev:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    use_gloo = same_dev or os.environ.get("GVEC_BENCH_DIST_INIT") == "gloo"
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher made WORLD_SIZE={world} ranks")
     dist = None
@@ -350,8 +357,8 @@ def main():
         sys.stdout.flush()
         saved_fd1 = os.dup(1)
         os.dup2(2, 1)
-        if os.environ.get("GVEC_BENCH_DIST_INIT") == "gloo":
-            dist.init_process_group("gloo")   # diagnostics only (scripts/rccl_tax.sh)
+        if use_gloo:
+            dist.init_process_group("gloo")   # diagnostics only (scripts/rccl_tax.sh, GVEC_BENCH_SAME_DEVICE)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
         # RCCL builds a communicator's channels and loads its kernels at the FIRST collective: ~16 ms during which the GPU
@@ -392,7 +399,24 @@ def main():
         # Two slabs alternate so step k+1's records never wait for step k's gather on the side stream.
         from generalsreinforcementlearning_amd.sharding import RecordGather
         ge = gather_slab_envs(args, world)
-        rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)] if ge > 0 else None
+        if use_gloo:
+            class _HostStagedGather(RecordGather):   # gloo has no CUDA gather: device slab -> pinned host -> gloo -> device slabs on rank 0
+                def __init__(self, nbytes):
+                    super().__init__(nbytes, torch.device("cpu"), dst=0)
+                    self.h_send, self.h_recv = self.send.pin_memory(), self.recv
+                    self.send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    self.recv = [torch.empty_like(self.send) for _ in range(self.world)] if self.rank == 0 else None
+
+                def gather(self):
+                    self.h_send.copy_(self.send)
+                    dist.gather(self.h_send, self.h_recv, dst=0)
+                    if self.rank == 0:
+                        for d, hsrc in zip(self.recv, self.h_recv):
+                            d.copy_(hsrc)
+                    return self.recv
+            rgs = [_HostStagedGather(ge * eng.experience_record_bytes()) for _ in range(2)] if ge > 0 else None
+        else:
+            rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)] if ge > 0 else None
         slab_free = [None, None]
         side = torch.cuda.Stream()
         if rgs is not None:
@@ -460,10 +484,11 @@ def main():
     played1 = eng.counters()
     played = {k: played1[k] - played0[k] for k in played1}   # turns the engines actually played inside the timed region
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if use_gloo else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([played["env_steps"], played["aborted_turns"], played["games_finished"]], dtype=torch.int64, device=dev)
+        c = torch.tensor([played["env_steps"], played["aborted_turns"], played["games_finished"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         played = dict(zip(("env_steps", "aborted_turns", "games_finished"), (int(v) for v in c.tolist())))
 
@@ -484,17 +509,25 @@ def main():
     if rgs is not None and rank == 0:
         # the consumer side, outside the timed region: expand the last gathered slabs into Experience fields
         import bisect
-        from generalsreinforcementlearning_amd.experience import decode_records
+        from generalsreinforcementlearning_amd.experience import expand_records_device
         torch.cuda.synchronize()
         lay = eng.experience_record_layout()
         n_g = (args.warmup + args.steps) // K                      # gathers so far; the last one filled slab (n_g - 1) & 1
         last = rgs[(n_g - 1) & 1].recv if n_g > 0 else []
-        decs = [decode_records(t.cpu().numpy(), lay, drop_invalid=True) for t in last]
+        # the GPU-side consumer (gvec_expand_experience_records): records -> StateToTensor x2 + action mask + scalars, on this GPU
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        decs = [expand_records_device(t, lay) for t in last]
+        x1.record()
+        torch.cuda.synchronize()
+        n_exp = int(sum(len(d["env"]) for d in decs))
+        envs_seen = torch.cat([d["env"] for d in decs]).cpu().tolist() if decs else []
         begins = [shard_plan(args, world, r)[3] for r in range(world)]   # first global env id of every rank
         gathered = {"record_bytes": eng.experience_record_bytes(), "records_per_rank_per_gather": ge,
                     "gather_every_steps": K,
-                    "experiences_decoded_last_step": int(sum(len(d["env"]) for d in decs)),
-                    "ranks_seen": sorted({bisect.bisect_right(begins, int(e)) - 1 for d in decs for e in d["env"]})}
+                    "experiences_decoded_last_step": n_exp,
+                    "expand_ms": x0.elapsed_time(x1), "expanded_bytes": n_exp * (2 * 9 + 1) * lay["stride"] * 4,
+                    "ranks_seen": sorted({bisect.bisect_right(begins, int(e)) - 1 for e in envs_seen})}
     if rank == 0:
         n = world
         kernel_s = kernel_ms / 1e3
@@ -560,6 +593,8 @@ def main():
                                  "float4 copy reaches on this part; traffic*: PMC-measured HBM bytes of this build; contract_*: SURVEY 8(d)'s "
                                  "7,280-B algorithmic figure (int32 armies, lists always stored), which this kernel undercuts - it can pass 1"},
         }
+        if same_dev:
+            out["rehearsal_same_device"] = True   # N ranks on ONE GPU over gloo: a choreography check, not a measurement
         if gathered:
             out["experience_gather"] = gathered
             out["roofline"]["kernel_ms_note"] = ("HIP-event span / steps on the compute stream: with the experience gather on it also holds the "
