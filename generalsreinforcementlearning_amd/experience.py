@@ -136,38 +136,61 @@ def decode_records(slab, layout, drop_invalid=True):
     return res
 
 
+class RecordExpander:
+    """decode_records on the GPU (gvec_expand_experience_records) with its output buffers kept: a consumer that expands a
+    slab of k records every few steps allocates once.  `expand(records)` fills, for every (record, player) slot, record-major,
+    state / next_state float32 [k * MP, 9 * stride] (an experience's own [9, H, W] at the start of its row), action_mask
+    uint8 [k * MP, 4 * stride] and meta int32 [k * MP, 8] (present, env id, player, turn, action, reward bits, done,
+    W | H << 8) and returns them as a dict of views; `compact(...)` turns that into decode_records' batch dict (torch
+    tensors, one entry per slot that holds an experience).  The kernel runs at HBM speed (57.6 KB written per experience
+    at 20x20); decode_records' per-record numpy loop is the readable twin the tests compare it with."""
+
+    def __init__(self, layout, max_records, device):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        self._t, self._C, self._lib, self.L = torch, C, _lib, _lib.load()
+        self.layout, self.max_records, self.device = dict(layout), int(max_records), torch.device(device)
+        rd, mp, stride = layout["record_dw"], layout["mp"], layout["stride"]
+        self._lay = (C.c_int32 * 8)(rd, mp, layout["fd"], layout["ns"], layout["max_players"], stride, 0, 0)
+        n = self.max_records * mp
+        self.state = torch.empty((n, 9 * stride), dtype=torch.float32, device=self.device)
+        self.next_state = torch.empty_like(self.state)
+        self.mask = torch.empty((n, 4 * stride), dtype=torch.uint8, device=self.device)
+        self.meta = torch.empty((n, 8), dtype=torch.int32, device=self.device)
+
+    def expand(self, records, stream=None):
+        t, C = self._t, self._C
+        flat = records.contiguous().view(t.uint8).reshape(-1)
+        k = flat.numel() // (self.layout["record_dw"] * 4)
+        if k > self.max_records or flat.device != self.device:
+            raise ValueError(f"{k} records on {flat.device}: this expander holds {self.max_records} on {self.device}")
+        s = t.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        self._lib.check(self.L.gvec_expand_experience_records(self.device.index or 0, C.c_void_p(int(s)), self._lay, C.c_void_p(flat.data_ptr()), k,
+                                                              C.c_void_p(self.state.data_ptr()), C.c_void_p(self.next_state.data_ptr()),
+                                                              C.c_void_p(self.mask.data_ptr()), C.c_void_p(self.meta.data_ptr())),
+                        "gvec_expand_experience_records")
+        n = k * self.layout["mp"]
+        return {"state": self.state[:n], "next_state": self.next_state[:n], "action_mask": self.mask[:n], "meta": self.meta[:n]}
+
+    def compact(self, slots):
+        t = self._t
+        keep = t.nonzero(slots["meta"][:, 0] != 0).reshape(-1)
+        m = slots["meta"][keep]
+        return {"env": m[:, 1].to(t.int64), "player_id": m[:, 2], "turn": m[:, 3], "action": m[:, 4],
+                "reward": m[:, 5].contiguous().view(t.float32), "done": m[:, 6] != 0, "width": (m[:, 7] & 0xFF).to(t.int64),
+                "height": ((m[:, 7] >> 8) & 0xFF).to(t.int64), "state": slots["state"][keep], "next_state": slots["next_state"][keep],
+                "action_mask": slots["action_mask"][keep].view(t.bool)}
+
+
 def expand_records_device(records, layout, stream=None):
-    """decode_records on the GPU (gvec_expand_experience_records): `records` a CUDA uint8 / int32 tensor holding k records
-    back to back, e.g. what RecordGather / gvec_gather_experience_records delivered.  Returns the same batch dict as
-    decode_records - torch tensors on the records' device, one entry per (record, player) that acted, record-major:
-    state / next_state float32 [K, 9 * stride] (an experience's own [9, H, W] at the start of its row), action_mask bool
-    [K, 4 * stride], env, player_id, turn, action, reward (float32), done, width, height.  The expansion runs at HBM speed
-    (28.8 KB per experience at 20x20); decode_records' per-record numpy loop is the readable twin the tests compare it with."""
-    import ctypes as C
-
-    import torch
-
-    from . import _lib
-    L = _lib.load()
-    rd, mp, stride = layout["record_dw"], layout["mp"], layout["stride"]
-    flat = records.contiguous().view(torch.uint8).reshape(-1)
-    n = flat.numel() // (rd * 4)
-    dev = flat.device
-    lay = (C.c_int32 * 8)(rd, mp, layout["fd"], layout["ns"], layout["max_players"], stride, 0, 0)
-    state = torch.empty((n * mp, 9 * stride), dtype=torch.float32, device=dev)
-    nxt = torch.empty_like(state)
-    mask = torch.empty((n * mp, 4 * stride), dtype=torch.uint8, device=dev)
-    meta = torch.empty((n * mp, 8), dtype=torch.int32, device=dev)
-    s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-    _lib.check(L.gvec_expand_experience_records(dev.index or 0, C.c_void_p(int(s)), lay, C.c_void_p(flat.data_ptr()), n, C.c_void_p(state.data_ptr()),
-                                                C.c_void_p(nxt.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(meta.data_ptr())),
-               "gvec_expand_experience_records")
-    keep = torch.nonzero(meta[:, 0] != 0).reshape(-1)
-    m = meta[keep]
-    return {"env": m[:, 1].to(torch.int64), "player_id": m[:, 2], "turn": m[:, 3], "action": m[:, 4],
-            "reward": m[:, 5].contiguous().view(torch.float32), "done": m[:, 6] != 0, "width": (m[:, 7] & 0xFF).to(torch.int64),
-            "height": ((m[:, 7] >> 8) & 0xFF).to(torch.int64), "state": state[keep], "next_state": nxt[keep],
-            "action_mask": mask[keep].view(torch.bool)}
+    """One-shot form: `records` a CUDA uint8 / int32 tensor holding k records back to back (what RecordGather /
+    gvec_gather_experience_records delivered) -> decode_records' batch dict as torch tensors on that device."""
+    k = records.numel() * records.element_size() // (layout["record_dw"] * 4)
+    ex = RecordExpander(layout, max(1, k), records.device)
+    return ex.compact(ex.expand(records, stream))
 
 
 class ExperienceBatcher:
