@@ -1263,7 +1263,7 @@ int32_t gvec_expand_experience_records(int32_t device, void* hip_stream, const i
   if (!layout8 || !records || !state || !next_state || !action_mask || !meta || n < 0) return GVEC_E_INVALID;
   const int rd = layout8[0], mp = layout8[1], fd = layout8[2], ns = layout8[3], stride = layout8[5];
   if (mp < 1 || mp > GVEC_MAX_PLAYERS || fd < 1 || fd > 32 || ns < 1 || ns > 16 || stride < 1 || stride > GVEC_MAX_DIM * GVEC_MAX_DIM ||
-      stride > 32 * fd || stride > 64 * ns || rd < 4 + 2 * mp + (8 * mp + 3) * fd + ns * 64) {
+      stride > 32 * fd || stride > 64 * ns || rd < 4 + 2 * mp + (8 * mp + 3) * fd + ns * 64 || rd > 4 + 2 * mp + (8 * mp + 3) * fd + ns * 64 + 3) {
     set_err("gvec_expand_experience_records: layout {%d, %d, %d, %d, ., %d} is not one gvec_experience_record_layout produces", rd, mp, fd, ns, stride);
     return GVEC_E_INVALID;
   }

@@ -601,19 +601,17 @@ struct ExpandArgs {
   int32_t n, record_dw, mp, fd, ns, stride;
 };
 
-__device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own, const uint32_t* vis, const uint32_t* types, const uint16_t* army,
-                                              int p, int P, int mp, int fd, int N, int stride, bool fog) {
+// own / vis / types / army: this wave's LDS copy of the record; any: OR of the P ownership planes
+__device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own_p, const uint32_t* any, const uint32_t* vis_p, const uint32_t* types,
+                                              const uint16_t* army, int fd, int N, int stride, bool fog) {
   const int lane = lane_id();
-  for (int t0 = 0; t0 < stride; t0 += 64) {
+  for (int t0 = 0; t0 < N; t0 += 64) {
     const int t = t0 + lane;
     if (t < N) {
       const int dwi = t >> 5;
       const uint32_t bit = 1u << (t & 31);
-      bool owned = false;
-      for (int q = 0; q < P; ++q) owned |= (own[q * fd + dwi] & bit) != 0u;
-      const bool mine = (own[p * fd + dwi] & bit) != 0u;
-      const bool seen = (vis[p * fd + dwi] & bit) != 0u;
-      const bool spec = ((types[0 * fd + dwi] | types[1 * fd + dwi]) & bit) != 0u, mount = (types[2 * fd + dwi] & bit) != 0u;
+      const bool owned = (any[dwi] & bit) != 0u, mine = (own_p[dwi] & bit) != 0u, seen = (vis_p[dwi] & bit) != 0u;
+      const bool spec = ((types[dwi] | types[fd + dwi]) & bit) != 0u, mount = (types[2 * fd + dwi] & bit) != 0u;
       const bool visible = !fog || seen;      // :50
       const bool open = visible && !mount;    // mountains short-circuit (:68-71)
       const int a = (int)army[t];
@@ -635,12 +633,19 @@ __device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own, c
   for (int i = 9 * N + lane; i < 9 * stride; i += 64) out[i] = 0.0f;  // a smaller board in a padded batch: clear the rest of the slot
 }
 
+// dynamic LDS: per wave the record (record_dw dwords) + two fd-dword "anybody owns it" planes (prev, next)
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void expand_records_kernel(ExpandArgs A) {
+  extern __shared__ uint32_t expand_lds[];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int i = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   if (i >= A.n) return;
-  const uint32_t* rec = A.records + (size_t)i * A.record_dw;
   const int mp = A.mp, fd = A.fd;
+  uint32_t* rec = expand_lds + (size_t)wave * (A.record_dw + 2 * fd);
+  {
+    const uint32_t* g = A.records + (size_t)i * A.record_dw;
+    for (int k = lane; k < A.record_dw; k += 64) rec[k] = g[k];
+  }
+  wave_lds_fence();
   const uint32_t r1 = rec[1];
   int W = (int)(r1 & 0xFFu), H = (int)((r1 >> 8) & 0xFFu), P = (int)((r1 >> 16) & 0xFFu);
   const uint32_t flags = r1 >> 24;
@@ -656,6 +661,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void expand_records_kernel(Ex
   const uint32_t* types = next_vis + mp * fd;   // general, city, mountain
   const uint16_t* army_prev = reinterpret_cast<const uint16_t*>(rec + off_prev);
   const uint16_t* army_next = reinterpret_cast<const uint16_t*>(rec + off_next);
+  uint32_t* any_prev = rec + A.record_dw;
+  uint32_t* any_next = any_prev + fd;
+  if (lane < fd) {
+    uint32_t a = 0u, b = 0u;
+    for (int q = 0; q < P; ++q) {
+      a |= prev_own[q * fd + lane];
+      b |= next_own[q * fd + lane];
+    }
+    any_prev[lane] = a;
+    any_next[lane] = b;
+  }
+  wave_lds_fence();
   for (int p = 0; p < mp; ++p) {
     const size_t slot = (size_t)i * mp + p;
     const bool present = p < P && ((acted >> p) & 1u) != 0u;
@@ -677,15 +694,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void expand_records_kernel(Ex
     uint8_t* mk = A.mask + slot * 4 * (size_t)A.stride;
     if (!present) {  // wave-uniform
       for (int k = lane; k < 9 * A.stride; k += 64) st[k] = nx[k] = 0.0f;
-      for (int k = lane; k < 4 * A.stride; k += 64) mk[k] = 0;
+      for (int k = lane; k < A.stride; k += 64) reinterpret_cast<uint32_t*>(mk)[k] = 0u;
       continue;
     }
-    expand_tensor(st, prev_own, prev_vis, types, army_prev, p, P, mp, fd, N, A.stride, (flags & 2u) != 0u);
-    expand_tensor(nx, next_own, next_vis, types, army_next, p, P, mp, fd, N, A.stride, (flags & 2u) != 0u);
+    expand_tensor(st, prev_own + p * fd, any_prev, prev_vis + p * fd, types, army_prev, fd, N, A.stride, (flags & 2u) != 0u);
+    expand_tensor(nx, next_own + p * fd, any_next, next_vis + p * fd, types, army_next, fd, N, A.stride, (flags & 2u) != 0u);
+    // GenerateActionMask as bytes, four per tile (t*4 + d): one dword store per tile
     const uint32_t* m = rec + off_mask + p * 4 * fd;   // [d][fd]
-    for (int k = lane; k < 4 * A.stride; k += 64) {
-      const int t = k >> 2, d = k & 3;
-      mk[k] = (uint8_t)((t < N) ? ((m[d * fd + (t >> 5)] >> (t & 31)) & 1u) : 0u);
+    for (int t = lane; t < A.stride; t += 64) {
+      uint32_t v = 0u;
+      if (t < N) {
+        const int dwi = t >> 5, sh = t & 31;
+        v = ((m[dwi] >> sh) & 1u) | (((m[fd + dwi] >> sh) & 1u) << 8) | (((m[2 * fd + dwi] >> sh) & 1u) << 16) | (((m[3 * fd + dwi] >> sh) & 1u) << 24);
+      }
+      st_stream<GVEC_NT_MASK>(reinterpret_cast<uint32_t*>(mk) + t, v);
     }
   }
 }
@@ -1705,7 +1727,8 @@ hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* 
   a.fd = layout8[2];
   a.ns = layout8[3];
   a.stride = layout8[5];
-  hipLaunchKernelGGL(expand_records_kernel, wave_grid(n), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  const size_t lds = (size_t)WAVES_PER_BLOCK * (a.record_dw + 2 * a.fd) * 4;   // <= 52 KB (32x32 8P)
+  hipLaunchKernelGGL(expand_records_kernel, wave_grid(n), dim3(64 * WAVES_PER_BLOCK), lds, s, a);
   return hipGetLastError();
 }
 hipError_t launch_observe(const Variant& v, const ExperienceArgs& a, hipStream_t s) {
