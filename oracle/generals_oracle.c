@@ -1003,24 +1003,25 @@ int32_t ora_batch_agent_actions(ora_batch* b, uint64_t seed, int32_t invalid_per
   return 0;
 }
 
-/* map generator: algorithm of mapgen/generator.go:64-253 on the build's counter RNG */
-typedef struct mrng { uint32_t key, ctr; } mrng;
-static inline uint32_t mdraw(mrng* r) { return ora_fmix32(r->key + (r->ctr++) * 0x9E3779B9u); }
-static inline int mintn(mrng* r, int n) { return (int)mulhi32(mdraw(r), (uint32_t)n); }
+/* ---- map generator: mapgen/generator.go:64-253 over an RNG interface ------------------------------------------------
+ * Two RNGs drive it: the build's counter RNG (ora_mapgen: what the device's parallel generator mirrors bit for bit) and
+ * Go's own math/rand (ora_mapgen_go: seed -> the board game.NewEngine starts from), below. */
+typedef struct map_rng {
+  void* st;
+  int (*intn)(void* st, int n);   /* rng.Intn(n) */
+  int (*shuf)(void* st, int n);   /* the j of rng.Shuffle's swap(i, j), n = i + 1 */
+} map_rng;
 
-int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t players,
-                   int32_t* army, int8_t* owner, uint8_t* type) {
+/* cfg: veins, min_len, max_len, city_ratio, city_army, spacing, stages (1 mountains | 2 cities | 4 generals) */
+static int32_t mapgen_with(map_rng* R, int w, int h, int players, const int32_t* cfg, int32_t* army, int8_t* owner, uint8_t* type) {
   int n = w * h;
-  mrng r; r.key = ora_fmix32(env_key(seed, (uint32_t)env) ^ 0x5BD1E995u); r.ctr = 0;
+  int veins = cfg[0], min_len = cfg[1], max_len = cfg[2], city_ratio = cfg[3], city_army = cfg[4], spacing = cfg[5], stages = cfg[6];
   for (int i = 0; i < n; i++) { army[i] = 0; owner[i] = -1; type[i] = ORA_TILE_NORMAL; }
-  /* DefaultMapConfig, generator.go:25-47 with config.go:198-200 defaults */
-  int spacing = 5; if (spacing > w / 2 + h / 2) spacing = w / 2 + h / 2;
-  int veins = n / 50, min_len = 3, max_len = w / 4, city_ratio = 20, city_army = 40;
   /* placeMountains :77-142 */
-  for (int v = 0; v < veins; v++) {
+  for (int v = 0; v < veins && (stages & 1); v++) {
     int sx = -1, sy = -1, found = 0;
     for (int a = 0; a < 100; a++) {
-      int x = mintn(&r, w), y = mintn(&r, h);
+      int x = R->intn(R->st, w), y = R->intn(R->st, h);
       int idx = y * w + x;
       if (type[idx] == ORA_TILE_NORMAL && owner[idx] == -1) { sx = x; sy = y; found = 1; break; }
     }
@@ -1028,11 +1029,11 @@ int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t pla
     int cx = sx, cy = sy;
     type[cy * w + cx] = ORA_TILE_MOUNTAIN; army[cy * w + cx] = 0;
     int len = min_len;
-    if (max_len > min_len) len += mintn(&r, max_len - min_len + 1);
+    if (max_len > min_len) len += R->intn(R->st, max_len - min_len + 1);
     for (int i = 1; i < len; i++) {
       int dx[4] = {0, 1, 0, -1}, dy[4] = {-1, 0, 1, 0};
       for (int a = 3; a > 0; a--) {                          /* rand.Shuffle: Fisher-Yates from the top */
-        int j = mintn(&r, a + 1);
+        int j = R->shuf(R->st, a + 1);
         int t = dx[a]; dx[a] = dx[j]; dx[j] = t; t = dy[a]; dy[a] = dy[j]; dy[j] = t;
       }
       int cand_x[4], cand_y[4], nc = 0;
@@ -1044,16 +1045,16 @@ int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t pla
         }
       }
       if (nc == 0) break;
-      int pick = mintn(&r, nc);
+      int pick = R->intn(R->st, nc);
       cx = cand_x[pick]; cy = cand_y[pick];
       type[cy * w + cx] = ORA_TILE_MOUNTAIN; army[cy * w + cx] = 0;
     }
   }
   /* placeCities :144-164 */
-  {
+  if (stages & 2) {
     int want = n / city_ratio, placed = 0, attempts = 0, max_attempts = want * 20;
     while (placed < want && attempts < max_attempts) {
-      int x = mintn(&r, w), y = mintn(&r, h);
+      int x = R->intn(R->st, w), y = R->intn(R->st, h);
       int idx = y * w + x;
       if (owner[idx] == -1 && type[idx] == ORA_TILE_NORMAL) { type[idx] = ORA_TILE_CITY; army[idx] = city_army; placed++; }
       attempts++;
@@ -1061,10 +1062,10 @@ int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t pla
   }
   /* placeGenerals :166-253 */
   int gx[32], gy[32];
-  for (int pid = 0; pid < players; pid++) {
+  for (int pid = 0; pid < players && (stages & 4); pid++) {
     int placed_idx = -1;
     for (int a = 0; a < n; a++) {
-      int x = mintn(&r, w), y = mintn(&r, h);
+      int x = R->intn(R->st, w), y = R->intn(R->st, h);
       int idx = y * w + x;
       if (owner[idx] != -1 || type[idx] != ORA_TILE_NORMAL) continue;
       int ok = 1;
@@ -1092,6 +1093,114 @@ int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t pla
     gx[pid] = placed_idx % w; gy[pid] = placed_idx / w;
   }
   return 0;
+}
+
+/* DefaultMapConfig, generator.go:25-47 with config.go:198-200 defaults */
+static void default_map_cfg(int w, int h, int32_t* cfg) {
+  int spacing = 5; if (spacing > w / 2 + h / 2) spacing = w / 2 + h / 2;
+  cfg[0] = (w * h) / 50; cfg[1] = 3; cfg[2] = w / 4; cfg[3] = 20; cfg[4] = 40; cfg[5] = spacing; cfg[6] = 7;
+}
+
+/* the build's counter RNG */
+typedef struct mrng { uint32_t key, ctr; } mrng;
+static inline uint32_t mdraw(mrng* r) { return ora_fmix32(r->key + (r->ctr++) * 0x9E3779B9u); }
+static int mintn(void* r, int n) { return (int)mulhi32(mdraw((mrng*)r), (uint32_t)n); }
+
+int32_t ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t players,
+                   int32_t* army, int8_t* owner, uint8_t* type) {
+  mrng r; r.key = ora_fmix32(env_key(seed, (uint32_t)env) ^ 0x5BD1E995u); r.ctr = 0;
+  map_rng R = {&r, mintn, mintn};
+  int32_t cfg[7];
+  default_map_cfg(w, h, cfg);
+  return mapgen_with(&R, w, h, players, cfg, army, owner, type);
+}
+
+/* ---- Go's math/rand (go.mod:3: go 1.24.0), restated from its published algorithm ----------------------------------
+ * rand.New(rand.NewSource(seed)): an additive lagged Fibonacci generator x[n] = x[n-607] + x[n-273] mod 2^64 (rng.go:
+ * rngLen 607, rngTap 273), seeded by the LCG x = 48271 x mod (2^31 - 1) - three draws per word, shifted 40 / 20 / 0 -
+ * XORed with the 607-word table rngCooked.  The table is derived, not copied: scripts/gen_go_rand_cooked.py.
+ * Int63 = low 63 bits; Int31 = Int63 >> 32; Int31n(n): mask for powers of two, else rejection above
+ * 2^31 - 1 - 2^31 % n, then % n; Intn(n) = Int31n for n < 2^31; Shuffle's j = int31n(i + 1): Lemire's multiply-shift on
+ * Uint32 = Int63 >> 31 with rejection below (-n) % n.
+ * Pinned by: Seed(1) -> Intn(100) = 81 87 47 59 81 18 25 40 56 0 (Go's well-known default sequence) and, through
+ * ora_mapgen_go, the reference's seed-12345 vectors (mapgen/generator_test.go:61-85, :396-455). */
+static const uint64_t go_rng_cooked[607] = {
+#include "go_rand_cooked.inc"
+};
+struct ora_gorand { uint64_t vec[607]; int tap, feed; };
+
+static int32_t go_seedrand(int32_t x) {
+  int32_t hi = x / 44488, lo = x % 44488;
+  x = 48271 * lo - 3399 * hi;
+  if (x < 0) x += 2147483647;
+  return x;
+}
+void ora_gorand_seed(ora_gorand* r, int64_t seed) {
+  r->tap = 0; r->feed = 607 - 273;
+  seed %= 2147483647;
+  if (seed < 0) seed += 2147483647;
+  if (seed == 0) seed = 89482311;
+  int32_t x = (int32_t)seed;
+  for (int i = -20; i < 607; i++) {
+    x = go_seedrand(x);
+    if (i >= 0) {
+      uint64_t u = (uint64_t)x << 40;
+      x = go_seedrand(x); u ^= (uint64_t)x << 20;
+      x = go_seedrand(x); u ^= (uint64_t)x;
+      r->vec[i] = u ^ go_rng_cooked[i];
+    }
+  }
+}
+int64_t ora_gorand_int63(ora_gorand* r) {
+  if (--r->tap < 0) r->tap += 607;
+  if (--r->feed < 0) r->feed += 607;
+  uint64_t x = r->vec[r->feed] + r->vec[r->tap];
+  r->vec[r->feed] = x;
+  return (int64_t)(x & 0x7FFFFFFFFFFFFFFFull);
+}
+int32_t ora_gorand_intn(ora_gorand* r, int32_t n) {            /* Intn -> Int31n */
+  if ((n & (n - 1)) == 0) return (int32_t)(ora_gorand_int63(r) >> 32) & (n - 1);
+  int32_t max = (int32_t)(2147483647u - (2147483648u % (uint32_t)n));
+  int32_t v = (int32_t)(ora_gorand_int63(r) >> 32);
+  while (v > max) v = (int32_t)(ora_gorand_int63(r) >> 32);
+  return v % n;
+}
+static int32_t go_int31n(ora_gorand* r, int32_t n) {            /* rand.go int31n (Shuffle, Perm) */
+  uint32_t v = (uint32_t)(ora_gorand_int63(r) >> 31);
+  uint64_t prod = (uint64_t)v * (uint64_t)(uint32_t)n;
+  uint32_t low = (uint32_t)prod;
+  if (low < (uint32_t)n) {
+    uint32_t thresh = (uint32_t)(-n) % (uint32_t)n;
+    while (low < thresh) {
+      v = (uint32_t)(ora_gorand_int63(r) >> 31);
+      prod = (uint64_t)v * (uint64_t)(uint32_t)n;
+      low = (uint32_t)prod;
+    }
+  }
+  return (int32_t)(prod >> 32);
+}
+ora_gorand* ora_gorand_new(int64_t seed) {
+  ora_gorand* r = (ora_gorand*)malloc(sizeof(ora_gorand));
+  ora_gorand_seed(r, seed);
+  return r;
+}
+void ora_gorand_free(ora_gorand* r) { free(r); }
+static int go_intn_cb(void* r, int n) { return ora_gorand_intn((ora_gorand*)r, n); }
+static int go_shuf_cb(void* r, int n) { return go_int31n((ora_gorand*)r, n); }
+
+/* mapgen.NewGenerator(cfg, rand.New(rand.NewSource(seed))).GenerateMap() (generator.go:56-75).  cfg7 NULL:
+ * DefaultMapConfig(w, h, players) - then this is the board game.NewEngine(ctx, GameConfig{Width, Height, Players,
+ * Rng: rand.New(rand.NewSource(seed))}) starts from (engine_initializer.go:106-110) - else {veins, min_len, max_len,
+ * city_ratio, city_army, spacing, stages} as the reference's tests override them. */
+int32_t ora_mapgen_go(int64_t seed, int32_t w, int32_t h, int32_t players, const int32_t* cfg7,
+                      int32_t* army, int8_t* owner, uint8_t* type) {
+  ora_gorand* r = ora_gorand_new(seed);
+  map_rng R = {r, go_intn_cb, go_shuf_cb};
+  int32_t cfg[7];
+  if (cfg7) memcpy(cfg, cfg7, sizeof cfg); else default_map_cfg(w, h, cfg);
+  int32_t rc = mapgen_with(&R, w, h, players, cfg, army, owner, type);
+  ora_gorand_free(r);
+  return rc;
 }
 
 /* auto-reset pool: board j = ora_mapgen(pool_seed, j, pool_w[j], pool_h[j], pool_p[j]) */

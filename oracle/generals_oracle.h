@@ -180,6 +180,15 @@ uint32_t   ora_amix(uint32_t x);      /* the random agent's mixer (24-bit multip
 int32_t    ora_batch_set_agent_mix(ora_batch* b, int32_t noop_per_65536, int32_t half_per_65536);
 int32_t    ora_batch_agent_actions(ora_batch* b, uint64_t seed, int32_t invalid_permille, ora_action8* actions, int32_t threads);
 /* map generator (algorithm of mapgen/generator.go:64-253, own counter RNG) */
+/* Go's math/rand (rand.New(rand.NewSource(seed))) and the reference's generator on it: see generals_oracle.c */
+typedef struct ora_gorand ora_gorand;
+ora_gorand* ora_gorand_new(int64_t seed);
+void       ora_gorand_free(ora_gorand* r);
+void       ora_gorand_seed(ora_gorand* r, int64_t seed);
+int64_t    ora_gorand_int63(ora_gorand* r);
+int32_t    ora_gorand_intn(ora_gorand* r, int32_t n);
+int32_t    ora_mapgen_go(int64_t seed, int32_t w, int32_t h, int32_t players, const int32_t* cfg7 /*NULL: DefaultMapConfig*/,
+                         int32_t* army, int8_t* owner, uint8_t* type);
 int32_t    ora_mapgen(uint64_t seed, int32_t env, int32_t w, int32_t h, int32_t players,
                       int32_t* army, int8_t* owner, uint8_t* type);
 /* auto-reset pool (= gvec_build_board_pool): board j = ora_mapgen(seed, j, w[j], h[j], p[j]);

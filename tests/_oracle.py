@@ -396,6 +396,45 @@ class OracleBatch:
                                  self.L.ora_engine_num_players(e))
 
 
+def mapgen_go(seed, w, h, players, cfg=None, stride=None):
+    """mapgen.NewGenerator(cfg, rand.New(rand.NewSource(seed))).GenerateMap() on the oracle's restatement of Go's math/rand.
+    cfg None = DefaultMapConfig; else [veins, min_len, max_len, city_ratio, city_army, spacing, stages]."""
+    n = stride or w * h
+    army, owner, typ = np.zeros(n, np.int32), np.full(n, -1, np.int8), np.zeros(n, np.uint8)
+    L = lib()
+    L.ora_mapgen_go.restype = C.c_int32
+    L.ora_mapgen_go.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, i8p, u8p]
+    c = None if cfg is None else np.ascontiguousarray(cfg, np.int32)
+    rc = L.ora_mapgen_go(seed, w, h, players, _ptr(c, i32p), _ptr(army, i32p), _ptr(owner, i8p), _ptr(typ, u8p))
+    return rc, army, owner, typ
+
+
+class GoRand:
+    """rand.New(rand.NewSource(seed)) as the oracle restates it."""
+
+    def __init__(self, seed):
+        self.L = lib()
+        self.L.ora_gorand_new.restype = C.c_void_p
+        self.L.ora_gorand_new.argtypes = [C.c_int64]
+        self.L.ora_gorand_intn.restype = C.c_int32
+        self.L.ora_gorand_intn.argtypes = [C.c_void_p, C.c_int32]
+        self.L.ora_gorand_int63.restype = C.c_int64
+        self.L.ora_gorand_int63.argtypes = [C.c_void_p]
+        self.L.ora_gorand_free.argtypes = [C.c_void_p]
+        self.r = self.L.ora_gorand_new(seed)
+
+    def intn(self, n):
+        return int(self.L.ora_gorand_intn(self.r, n))
+
+    def int63(self):
+        return int(self.L.ora_gorand_int63(self.r))
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            self.L.ora_gorand_free(self.r)
+            self.r = None
+
+
 def mapgen(seed, env, w, h, players, stride=None):
     n = stride or w * h
     army = np.zeros(n, np.int32)

@@ -1,0 +1,78 @@
+"""Go's math/rand, restated (oracle/generals_oracle.c "Go's math/rand"; table: scripts/gen_go_rand_cooked.py), and the
+reference's map generator on it - which makes seed -> board parity with the Go engine checkable without a Go toolchain:
+
+  * Seed(1) -> Intn(100) x 10 = 81 87 47 59 81 18 25 40 56 0, Go's well-known default sequence;
+  * the generator script's derivation re-run here (jump-ahead == the committed table; both .inc files identical);
+  * mapgen/generator_test.go's two seed-12345 assertions (22 mountains; 58 mountains + 20 cities + 4 spaced generals),
+    the only places where the reference pins its RNG stream (tests/golden/reference_kats.json, kind mapgen_seeded);
+  * the RNG-independent assertions of generator_test.go on Go-seeded boards (seeds 0..49 on 5x5 never fail, :27-46)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from test_oracle_golden import by_kind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_go_rand_default_sequence():
+    r = O.GoRand(1)
+    assert [r.intn(100) for _ in range(10)] == [81, 87, 47, 59, 81, 18, 25, 40, 56, 0]
+    # Int31n's two branches: powers of two mask, everything else rejects and reduces
+    r = O.GoRand(42)
+    assert all(0 <= r.intn(n) < n for n in (1, 2, 3, 7, 8, 20, 25, 1000, 1 << 20, (1 << 31) - 1) for _ in range(50))
+    assert all(0 <= O.GoRand(s).int63() < 1 << 63 for s in (0, -5, 1 << 40, 2147483647, 2147483648))
+    # Seed reduces mod 2^31 - 1 and maps 0 to 89482311 (rng.go Seed)
+    assert O.GoRand(0).int63() == O.GoRand(2147483647).int63() == O.GoRand(89482311).int63()
+    assert O.GoRand(5).int63() == O.GoRand(5 + 2147483647).int63() != O.GoRand(6).int63()
+
+
+def test_cooked_table_is_what_the_script_derives():
+    a = open(os.path.join(ROOT, "oracle", "go_rand_cooked.inc")).read()
+    b = open(os.path.join(ROOT, "generalsreinforcementlearning_amd", "csrc", "go_rand_cooked.inc")).read()
+    assert a == b
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_go_rand_cooked as G
+    cooked = G.advance(G.seed_vector(1, 20, 10), 7_800_000_000_000)
+    words = [int(w.rstrip("ull,"), 16) for w in a.split() if w.startswith("0x")]
+    assert words == cooked and len(words) == 607
+
+
+@pytest.mark.parametrize("c", by_kind("mapgen_seeded"))
+def test_reference_seeded_vectors(c):
+    w, h, e = c["w"], c["h"], c["expect"]
+    rc, army, owner, typ = O.mapgen_go(c["seed"], w, h, c["players"], c["cfg"])
+    assert rc == 0
+    assert int((typ == 3).sum()) == e["mountains"] and int((typ == 2).sum()) == e["cities"] and int((typ == 1).sum()) == e["generals"]
+    assert (army[typ == 3] == 0).all() and (owner[typ == 3] == -1).all()                    # generator_test.go:75-79
+    if e["cities"]:
+        assert (army[typ == 2] == e["city_army"]).all() and (owner[typ == 2] == -1).all()   # :428-431
+    if e["generals"]:
+        g = np.flatnonzero(typ == 1)
+        assert (army[g] == e["general_army"]).all() and sorted(owner[g]) == list(range(e["generals"]))   # :421-426
+        for i in range(len(g)):
+            for j in range(i + 1, len(g)):
+                assert abs(g[i] % w - g[j] % w) + abs(g[i] // w - g[j] // w) >= e["min_spacing"]          # :446-455
+    assert (army[(typ == 0)] == 0).all() and (owner[typ == 0] == -1).all()                  # :436-439
+
+
+def test_default_config_boards_from_go_seeds():
+    """DefaultMapConfig boards (what game.NewEngine builds from GameConfig.Rng): generator_test.go:27-46 - a 5x5 2-player
+    board never fails, whatever the seed - and the default ratios on the BASELINE sizes."""
+    for seed in range(50):
+        rc, army, owner, typ = O.mapgen_go(seed, 5, 5, 2)
+        assert rc == 0 and int((typ == 1).sum()) == 2
+    for (w, h, p) in ((10, 10, 2), (15, 15, 2), (20, 20, 4)):
+        for seed in (1, 2, 3, 12345):
+            rc, army, owner, typ = O.mapgen_go(seed, w, h, p)
+            assert rc == 0 and int((typ == 1).sum()) == p and int((typ == 2).sum()) == (w * h) // 20
+            assert 0 < int((typ == 3).sum()) <= ((w * h) // 50) * max(3, w // 4)
+    a = O.mapgen_go(7, 20, 20, 4)
+    b = O.mapgen_go(7, 20, 20, 4)
+    assert all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+    c = O.mapgen_go(8, 20, 20, 4)
+    assert not np.array_equal(a[3], c[3])
