@@ -51,6 +51,7 @@ SYMBOLS = {
     "gvec_state_bytes_per_env": (C.c_int64, [_vp]),
     "gvec_reset": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "gvec_reset_generated": (_i32, [_vp, _u64, _vp, _vp, _vp]),
+    "gvec_reset_go_seeded": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "gvec_build_board_pool": (_i32, [_vp, _i32, _u64, _vp, _vp, _vp]),
     "gvec_step": (_i32, [_vp, _vp, _vp, _vp, _i32]),
     "gvec_legal_mask": (_i32, [_vp, _vp, _i32]),

@@ -722,8 +722,11 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int3
 }
 
 static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint32_t* army16, int32_t* army32, int count, uint64_t seed,
-                             const int32_t* width, const int32_t* height, const int32_t* players, int index_base = 0) {
-  const int chunk = 65536;
+                             const int32_t* width, const int32_t* height, const int32_t* players, int index_base = 0,
+                             const int64_t* go_seeds = nullptr) {
+  // Go-seeded boards carry a 607-word generator state each while they are being made: smaller chunks (80 MB of scratch)
+  const int chunk = go_seeds ? 16384 : 65536;
+  DevBuf b_gs(h, 10), b_gst(h, 11);
   DevBuf b_army(h, 1), b_owner(h, 2), b_type(h, 3), b_w(h, 4), b_h(h, 5), b_p(h, 6), b_iw(h, 7), b_ih(h, 8), b_ip(h, 9);
   const int cn = count < chunk ? count : chunk;
   HIPCHK(b_army.alloc((size_t)cn * h->stride * 4));
@@ -735,6 +738,10 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint
   if (width) HIPCHK(b_iw.alloc((size_t)cn * 4));
   if (height) HIPCHK(b_ih.alloc((size_t)cn * 4));
   if (players) HIPCHK(b_ip.alloc((size_t)cn * 4));
+  if (go_seeds) {
+    HIPCHK(b_gs.alloc((size_t)cn * 8));
+    HIPCHK(b_gst.alloc((size_t)cn * 607 * 8));
+  }
   for (int first = 0; first < count; first += chunk) {
     const int n = (count - first) < chunk ? (count - first) : chunk;
     if (width) HIPCHK(hipMemcpyAsync(b_iw.p, width + first, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -760,6 +767,11 @@ static int32_t generate_into(gvec_handle* h, uint32_t* hdr, uint32_t* rows, uint
     m.seed_lo = (uint32_t)seed;
     m.seed_hi = (uint32_t)(seed >> 32);
     m.status = h->d_status;
+    if (go_seeds) {
+      HIPCHK(hipMemcpyAsync(b_gs.p, go_seeds + first, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+      m.go_seeds = b_gs.as<int64_t>();
+      m.go_state = b_gst.as<uint64_t>();
+    }
     HIPCHK(launch_mapgen(m, h->stream));
     gvec_state_view v;
     memset(&v, 0, sizeof v);
@@ -784,6 +796,17 @@ int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed, const int32_t* width
     });
   HIPCHK(hipSetDevice(h->cfg.device));
   RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->cfg.num_envs, seed, width, height, players, h->env_base));
+  return refresh_legal(h);
+}
+
+int32_t gvec_reset_go_seeded(gvec_handle* h, const int64_t* seeds, const int32_t* width, const int32_t* height, const int32_t* players) {
+  if (!h || !seeds) return GVEC_E_INVALID;
+  if (h->sharded())
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_reset_go_seeded(c, seeds + begin, width ? width + begin : nullptr, height ? height + begin : nullptr, players ? players + begin : nullptr);
+    });
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RET_IF(generate_into(h, h->d_hdr, h->d_rows, h->d_army16, h->d_army32, h->cfg.num_envs, 0, width, height, players, 0, seeds));
   return refresh_legal(h);
 }
 

@@ -1394,11 +1394,86 @@ struct MRng {
   uint32_t key, ctr;
   __device__ uint32_t draw() { return fmix32(key + (ctr++) * 0x9E3779B9u); }
   __device__ int intn(int n) { return (int)__umulhi(draw(), (uint32_t)n); }
+  __device__ int shuf(int n) { return intn(n); }
+  __device__ void begin(const MapgenArgs& A, int i) {
+    key = fmix32(env_key(A.seed_lo, A.seed_hi, (uint32_t)(A.first_index + i)) ^ 0x5BD1E995u);
+    ctr = 0u;
+  }
 };
 
-__global__ void mapgen_kernel(MapgenArgs A) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= A.n) return;
+// Go's math/rand - rand.New(rand.NewSource(seed)), go 1.24 - one generator per thread: the additive lagged Fibonacci
+// generator x[n] = x[n-607] + x[n-273] mod 2^64 seeded by the LCG x = 48271 x mod (2^31 - 1) XOR the 607-word table
+// (derived by scripts/gen_go_rand_cooked.py, not copied).  The 607-word state lives in a caller-provided global buffer,
+// word k of thread i at vec[k * stride] (threads seed in lock-step: coalesced).  Mirrored by the oracle's ora_gorand,
+// which the reference's own seed-12345 vectors pin (tests/test_go_rand.py).
+__device__ const uint64_t go_rng_cooked[607] = {
+#include "go_rand_cooked.inc"
+};
+struct GoRng {
+  uint64_t* vec;
+  size_t stride;
+  int tap, feed;
+  static __device__ int32_t seedrand(int32_t x) {
+    const int32_t hi = x / 44488, lo = x % 44488;
+    x = 48271 * lo - 3399 * hi;
+    return x < 0 ? x + 2147483647 : x;
+  }
+  __device__ void seed(int64_t s) {
+    tap = 0;
+    feed = 607 - 273;
+    s %= 2147483647ll;
+    if (s < 0) s += 2147483647ll;
+    if (s == 0) s = 89482311ll;
+    int32_t x = (int32_t)s;
+    for (int i = -20; i < 607; ++i) {
+      x = seedrand(x);
+      if (i >= 0) {
+        uint64_t u = (uint64_t)x << 40;
+        x = seedrand(x);
+        u ^= (uint64_t)x << 20;
+        x = seedrand(x);
+        u ^= (uint64_t)x;
+        vec[(size_t)i * stride] = u ^ go_rng_cooked[i];
+      }
+    }
+  }
+  __device__ uint64_t int63() {
+    if (--tap < 0) tap += 607;
+    if (--feed < 0) feed += 607;
+    const uint64_t x = vec[(size_t)feed * stride] + vec[(size_t)tap * stride];
+    vec[(size_t)feed * stride] = x;
+    return x & 0x7FFFFFFFFFFFFFFFull;
+  }
+  __device__ int intn(int n) {  // Intn -> Int31n
+    if ((n & (n - 1)) == 0) return (int)(int63() >> 32) & (n - 1);
+    const int32_t mx = (int32_t)(2147483647u - (2147483648u % (uint32_t)n));
+    int32_t v = (int32_t)(int63() >> 32);
+    while (v > mx) v = (int32_t)(int63() >> 32);
+    return v % n;
+  }
+  __device__ int shuf(int n) {  // rand.go int31n (Shuffle): Lemire's multiply-shift on Uint32
+    uint32_t v = (uint32_t)(int63() >> 31);
+    uint64_t prod = (uint64_t)v * (uint64_t)(uint32_t)n;
+    uint32_t low = (uint32_t)prod;
+    if (low < (uint32_t)n) {
+      const uint32_t thresh = (uint32_t)(-n) % (uint32_t)n;
+      while (low < thresh) {
+        v = (uint32_t)(int63() >> 31);
+        prod = (uint64_t)v * (uint64_t)(uint32_t)n;
+        low = (uint32_t)prod;
+      }
+    }
+    return (int)(prod >> 32);
+  }
+  __device__ void begin(const MapgenArgs& A, int i) {
+    vec = A.go_state + i;
+    stride = (size_t)A.n;
+    seed(A.go_seeds[i]);
+  }
+};
+
+template <typename RNG>
+__device__ __forceinline__ void mapgen_board(RNG& r, const MapgenArgs& A, int i) {
   const int w = A.in_width ? A.in_width[i] : A.max_w, h = A.in_height ? A.in_height[i] : A.max_h;
   const int players = A.in_players ? A.in_players[i] : A.max_p;
   A.width[i] = w;
@@ -1412,9 +1487,7 @@ __global__ void mapgen_kernel(MapgenArgs A) {
   int8_t* owner = A.owner + (size_t)i * A.stride;
   uint8_t* type = A.type + (size_t)i * A.stride;
   const int n = w * h;
-  MRng r;
-  r.key = fmix32(env_key(A.seed_lo, A.seed_hi, (uint32_t)(A.first_index + i)) ^ 0x5BD1E995u);
-  r.ctr = 0u;
+  r.begin(A, i);
   for (int t = 0; t < A.stride; ++t) {
     army[t] = 0;
     owner[t] = -1;
@@ -1443,7 +1516,7 @@ __global__ void mapgen_kernel(MapgenArgs A) {
       // dirs packed 2 bits each, N E S W = 0 1 2 3; rand.Shuffle = Fisher-Yates from the top (:117)
       uint32_t dirs = 0xE4u;  // [0]=0,[1]=1,[2]=2,[3]=3
       for (int a = 3; a > 0; --a) {
-        const int j = r.intn(a + 1);
+        const int j = r.shuf(a + 1);
         const uint32_t da = (dirs >> (2 * a)) & 3u, dj = (dirs >> (2 * j)) & 3u;
         dirs = (dirs & ~((3u << (2 * a)) | (3u << (2 * j))));
         dirs |= (dj << (2 * a)) | (da << (2 * j));
@@ -1511,6 +1584,20 @@ __global__ void mapgen_kernel(MapgenArgs A) {
     gx[pid] = placed_idx % w;
     gy[pid] = placed_idx / w;
   }
+}
+
+__global__ void mapgen_kernel(MapgenArgs A) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= A.n) return;
+  MRng r;
+  mapgen_board(r, A, i);
+}
+// the same generator on Go's math/rand: board i = what game.NewEngine builds from GameConfig.Rng = rand.New(rand.NewSource(go_seeds[i]))
+__global__ void mapgen_go_kernel(MapgenArgs A) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= A.n) return;
+  GoRng r;
+  mapgen_board(r, A, i);
 }
 
 // =========================================================================================
@@ -1768,7 +1855,8 @@ hipError_t launch_records(const Variant& v, const RecordArgs& a, bool import, hi
   });
 }
 hipError_t launch_mapgen(const MapgenArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(mapgen_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  if (a.go_seeds) hipLaunchKernelGGL(mapgen_go_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(mapgen_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_counter_sum(const uint32_t* hdr, int32_t num_envs, unsigned long long* out, hipStream_t s) {

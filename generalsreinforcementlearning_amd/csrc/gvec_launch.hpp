@@ -102,6 +102,10 @@ struct MapgenArgs {
   int32_t n, stride, max_w, max_h, max_p, first_index;
   uint32_t seed_lo, seed_hi;
   int32_t* status;
+  // Go-seeded generation (gvec_reset_go_seeded): non-null selects Go's math/rand, one seed per board;
+  // go_state: [607][n] u64 of scratch for the generators' vectors
+  const int64_t* go_seeds;
+  uint64_t* go_state;
 };
 
 // one turn per launch (KF_AGENT selects the on-device agent; the legal buffer must then be current)

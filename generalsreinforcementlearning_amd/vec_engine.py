@@ -148,6 +148,15 @@ class VecEngine:
         w, h, p = cv(width), cv(height), cv(players)
         check(self.L.gvec_reset_generated(self.h, seed, _ptr(w), _ptr(h), _ptr(p)), "gvec_reset_generated")
 
+    def reset_go_seeded(self, seeds, width=None, height=None, players=None):
+        """Env i starts from the board the Go engine builds from GameConfig.Rng = rand.New(rand.NewSource(seeds[i]))
+        (Go's math/rand restated on the device; include/generals_vec.h gvec_reset_go_seeded)."""
+        cv = lambda v: None if v is None else np.ascontiguousarray(v, np.int32)
+        w, h, p = cv(width), cv(height), cv(players)
+        sd = np.ascontiguousarray(seeds, np.int64)
+        assert sd.shape == (self.B,)
+        check(self.L.gvec_reset_go_seeded(self.h, _ptr(sd), _ptr(w), _ptr(h), _ptr(p)), "gvec_reset_go_seeded")
+
     def build_board_pool(self, pool_size, seed, width=None, height=None, players=None):
         cv = lambda v: None if v is None else np.ascontiguousarray(v, np.int32)
         w, h, p = cv(width), cv(height), cv(players)

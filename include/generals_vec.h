@@ -208,6 +208,17 @@ int32_t gvec_reset(gvec_handle* h, const int32_t* env_ids, int32_t n,
 int32_t gvec_reset_generated(gvec_handle* h, uint64_t seed,
                              const int32_t* width, const int32_t* height,
                              const int32_t* players);
+/* The same generator on Go's OWN math/rand: env i gets exactly the board
+ *     mapgen.NewGenerator(mapgen.DefaultMapConfig(W, H, P), rand.New(rand.NewSource(seeds[i]))).GenerateMap()
+ * builds (mapgen/generator.go:56-75) - i.e. the board game.NewEngine(ctx, GameConfig{Width, Height, Players, Rng:
+ * rand.New(rand.NewSource(seeds[i]))}) starts from (engine_initializer.go:106-110) - then the reset pass.  Go's generator
+ * (go 1.24: an additive lagged Fibonacci generator seeded through an LCG and a 607-word table) is restated from its
+ * published algorithm, the table derived (scripts/gen_go_rand_cooked.py), and the whole pinned by the reference's own
+ * seed-12345 tests (mapgen/generator_test.go:61-85, :396-455) through the oracle twin.  seeds: host int64 [B]; sizes as
+ * gvec_reset_generated.  A Go host can therefore build B reference engines from seeds and this handle from the same seeds
+ * and compare them from turn 0 (host/go/vecengine_diff_test.go). */
+int32_t gvec_reset_go_seeded(gvec_handle* h, const int64_t* seeds, const int32_t* width, const int32_t* height,
+                             const int32_t* players);
 /* Pool of pre-generated, pre-initialised boards used by auto_reset: board j is
  * generated with key (seed, j) and sizes width[j]/height[j]/players[j] (host arrays
  * [pool_size], NULL = max sizes).  A finished env spends its next step being

@@ -76,3 +76,44 @@ def test_default_config_boards_from_go_seeds():
     assert all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
     c = O.mapgen_go(8, 20, 20, 4)
     assert not np.array_equal(a[3], c[3])
+
+
+# ---- the device generator on Go's math/rand (gvec_reset_go_seeded) ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [[(20, 20, 4)], [(10, 10, 2)], [(5, 5, 2), (15, 15, 3), (20, 20, 4), (25, 25, 4), (32, 32, 8), (7, 30, 5)]],
+                         ids=["20x20_p4", "10x10_p2", "mixed_padded"])
+def test_device_boards_from_go_seeds_equal_the_oracle_s(sizes):
+    """gvec_reset_go_seeded: board i is what the oracle's restatement of Go's math/rand + generator builds from seeds[i] -
+    which the reference's seed-12345 vectors pin - and the engines then start identically (performInitialSetup)."""
+    import generalsreinforcementlearning_amd as g
+    import _harness as H
+    B = 300
+    per = [sizes[i % len(sizes)] for i in range(B)]
+    mw, mh, mp = max(s[0] for s in per), max(s[1] for s in per), max(s[2] for s in per)
+    rng = np.random.default_rng(5)
+    seeds = np.concatenate([[12345, 0, 1, -7, 2147483647, 2147483648, 1 << 40], rng.integers(-2 ** 62, 2 ** 62, B - 7)]).astype(np.int64)
+    ws, hs, ps = (np.array([s[k] for s in per], np.int32) for k in range(3))
+    eng = g.VecEngine(B, mw, mh, mp)
+    eng.reset_go_seeded(seeds, ws, hs, ps)
+    st = eng.game_state()
+    army = np.zeros((B, mw * mh), np.int32)
+    owner = np.full((B, mw * mh), -1, np.int8)
+    typ = np.zeros((B, mw * mh), np.uint8)
+    for i, (w, h, p) in enumerate(per):
+        rc, a, o, t = O.mapgen_go(int(seeds[i]), w, h, p, stride=mw * mh)
+        assert rc == 0
+        army[i], owner[i], typ[i] = a, o, t
+    for f, want in (("army", army), ("owner", owner), ("type", typ)):
+        assert np.array_equal(st[f], want), (f, np.flatnonzero((st[f] != want).any(1))[:8])
+    ora = O.OracleBatch(B, mw, mh, mp)
+    ora.reset(army, owner, typ, ws, hs, ps)
+    H.assert_states_equal(st, ora.read_state(), "after gvec_reset_go_seeded")
+    H.run_lockstep(eng, ora, 30, seed=2, invalid_permille=5, check_every=10, ctx="go-seeded boards")
+    # sharded handles hand every shard its slice of the seeds
+    many = g.VecEngine(B, mw, mh, mp, devices=[0, 0, 0])
+    many.reset_go_seeded(seeds, ws, hs, ps)
+    sm = many.game_state()
+    for f in ("army", "owner", "type", "visible", "listed"):
+        assert np.array_equal(sm[f], st[f]), f
+    many.close()
+    eng.close()
