@@ -124,6 +124,16 @@ func (e *VecEngine) ResetBoards(boards []*core.Board, players []int) error {
 	return apiErr(C.gvec_reset(e.h, nil, C.int32_t(n), &army[0], &owner[0], &typ[0], &w[0], &h[0], &p[0], C.GVEC_MEM_HOST), "gvec_reset")
 }
 
+// ResetGoSeeded builds env i's board on the GPU from Go's own math/rand stream: exactly the board
+// game.NewEngine(ctx, game.GameConfig{Width, Height, Players, Rng: rand.New(rand.NewSource(seeds[i]))}) starts from
+// (mapgen.DefaultMapConfig + GenerateMap, engine_initializer.go:106-110).  No board crosses PCIe.
+func (e *VecEngine) ResetGoSeeded(seeds []int64) error {
+	if len(seeds) != e.cfg.NumEnvs {
+		return fmt.Errorf("ResetGoSeeded: %d seeds for %d envs", len(seeds), e.cfg.NumEnvs)
+	}
+	return apiErr(C.gvec_reset_go_seeded(e.h, (*C.int64_t)(unsafe.Pointer(&seeds[0])), nil, nil, nil), "gvec_reset_go_seeded")
+}
+
 func clamp8(v int) C.int8_t {
 	if v < -128 {
 		v = -128

@@ -32,8 +32,29 @@ func TestVecEngineMatchesGoEngine(t *testing.T) {
 		t.Fatal(err)
 	}
 	defer vec.Close()
-	if err := vec.ResetBoards(boards, players); err != nil {
+	// The boards are NOT uploaded: the library regenerates them on the GPU from the same seeds with its restatement of
+	// Go's math/rand (gvec_reset_go_seeded) - so turn 0 already compares the reference's mapgen with the device's.
+	// (vec.ResetBoards(boards, players) is the upload path, for boards that come from anywhere else.)
+	_ = boards
+	_ = players
+	seeds := make([]int64, B)
+	for i := range seeds {
+		seeds[i] = int64(i + 1)
+	}
+	if err := vec.ResetGoSeeded(seeds); err != nil {
 		t.Fatal(err)
+	}
+	if st0, err := vec.GameState(0, B); err != nil {
+		t.Fatal(err)
+	} else {
+		for i := range ref {
+			for tIdx, tile := range ref[i].GameState().Board.T {
+				k := i*W*H + tIdx
+				if int(st0.Army[k]) != tile.Army || int(st0.Owner[k]) != tile.Owner || int(st0.Type[k]) != int(tile.Type) {
+					t.Fatalf("turn 0 env %d (seed %d) tile %d: go=%+v vec army=%d owner=%d type=%d", i, seeds[i], tIdx, tile, st0.Army[k], st0.Owner[k], st0.Type[k])
+				}
+			}
+		}
 	}
 	rng := rand.New(rand.NewSource(99))
 	for turn := 0; turn < turns; turn++ {
