@@ -117,3 +117,46 @@ def test_device_boards_from_go_seeds_equal_the_oracle_s(sizes):
         assert np.array_equal(sm[f], st[f]), f
     many.close()
     eng.close()
+
+
+# ---- engine_test.go on the boards the Go tests themselves build (NewEngine with Rng = rand.NewSource(12345)) ---------
+def _new_engine_checks(st, P):
+    """TestNewEngine (game/engine_test.go:24-63) on a state dict of one env."""
+    assert not st["done"][0] and st["turn"][0] == 0                       # :46-47
+    for i in range(P):
+        assert st["alive"][0, i]                                          # :52
+        gi = int(st["general_idx"][0, i])
+        assert gi != -1 and st["owner"][0, gi] == i and st["type"][0, gi] == 1   # :53-58
+        assert st["army_count"][0, i] >= 1                                # :60
+    assert int((st["type"][0] == 1).sum()) == P                           # :62
+
+
+def test_new_engine_on_the_go_tests_own_board_oracle():
+    rc, army, owner, typ = O.mapgen_go(12345, 8, 8, 2)
+    assert rc == 0
+    ora = O.OracleBatch(1, 8, 8, 2)
+    ora.reset(army[None], owner[None], typ[None], [8], [8], [2])
+    _new_engine_checks(ora.read_state(), 2)
+    # TestEngine_Step_BasicTurn (:65-86): NewEngine(5x5, 1 player, seed 12345), one Step without actions
+    rc, army, owner, typ = O.mapgen_go(12345, 5, 5, 1)
+    one = O.OracleBatch(1, 5, 5, 1)
+    one.reset(army[None], owner[None], typ[None], [5], [5], [1])
+    s0 = one.read_state()
+    acts = np.zeros((1, 1), O.ACTION_DTYPE)
+    assert one.step(acts)[0] == 0
+    s1 = one.read_state()
+    assert s1["turn"][0] == s0["turn"][0] + 1 and s1["army_count"][0, 0] == s0["army_count"][0, 0] + 1 and not s1["done"][0]   # :82-85
+
+
+@pytest.mark.gpu
+def test_new_engine_on_the_go_tests_own_board_hip():
+    import generalsreinforcementlearning_amd as g
+    eng = g.VecEngine(1, 8, 8, 2)
+    eng.reset_go_seeded([12345])
+    _new_engine_checks(eng.game_state(), 2)
+    one = g.VecEngine(1, 5, 5, 1)
+    one.reset_go_seeded([12345])
+    s0 = one.game_state()
+    assert one.step(g.make_actions(1, 1))[0] == 0
+    s1 = one.game_state()
+    assert s1["turn"][0] == s0["turn"][0] + 1 and s1["army_count"][0, 0] == s0["army_count"][0, 0] + 1 and not s1["done"][0]
