@@ -46,6 +46,49 @@ def action_index(a, w):
     return (int(a["from_y"]) * w + int(a["from_x"])) * 4 + d
 
 
+def flow_experience(i):
+    """A small deterministic Experience (3x2 board) for the queue / statistics / dataset flow."""
+    st = [float((i * 7 + k) % 5) / 4.0 for k in range(9 * 2 * 3)]
+    nx = [float((i * 3 + k) % 7) / 8.0 for k in range(9 * 2 * 3)]
+    return experience_pb2.Experience(experience_id=f"flow-{i}", game_id=f"game-{i % 3}", player_id=i % 2, turn=10 + i,
+                                     state=experience_pb2.TensorState(shape=[9, 2, 3], data=st), action=i % 24, reward=i * 0.25 - 1.0,
+                                     next_state=experience_pb2.TensorState(shape=[9, 2, 3], data=nx), done=(i % 5 == 4),
+                                     action_mask=[(i + k) % 3 == 0 for k in range(24)] if i % 4 else [])
+
+
+def client_flow():
+    """The reference client's queue, drop accounting, statistics, get_batch and ExperienceDataset on hand-built batches
+    (no server: _process_batch is what the stream worker calls per batch, experience_stream_client.py:105-110)."""
+    from experience_stream_client import ExperienceDataset
+    client = ExperienceStreamClient(ExperienceConfig(buffer_size=7))
+    sizes = [3, 4, 2, 5]                                   # 14 experiences into a queue of 7: the rest is dropped
+    i = 0
+    for bi, n in enumerate(sizes):
+        batch = experience_pb2.ExperienceBatch(batch_id=bi, stream_id="flow")
+        for _ in range(n):
+            batch.experiences.append(flow_experience(i))
+            i += 1
+        client._process_batch(experience_pb2.ExperienceBatch.FromString(batch.SerializeToString()))
+    stats = client.get_stats()
+    first = client.get_batch(4, timeout=1.0)
+    stats_after = client.get_stats()
+    ds = ExperienceDataset(client, buffer_size=5)
+    ds.fill_buffer(min_size=3)                              # drains the remaining 3
+    buf_ids = [e["experience_id"] for e in ds.buffer]
+    np.random.seed(3)
+    draw = [e["experience_id"] for e in ds.sample(2)]
+    short = [e["experience_id"] for e in ds.sample(9)]     # more than there is: the whole buffer
+    d0 = first[0]
+    return {"buffer_size": 7, "batch_sizes": sizes,
+            "stats": {k: stats[k] for k in ("total_experiences", "total_batches", "dropped_experiences", "queue_size", "streaming")},
+            "last_batch_time_is_float": isinstance(stats["last_batch_time"], float),
+            "get_batch_4": [e["experience_id"] for e in first], "queue_size_after": stats_after["queue_size"],
+            "dataset_buffer": buf_ids, "dataset_seed": 3, "dataset_sample_2": draw, "dataset_sample_9": short,
+            "first_types": {k: type(v).__name__ for k, v in d0.items()},
+            "first": {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in d0.items()},
+            "mask_none_ids": [e["experience_id"] for e in first if e["action_mask"] is None]}
+
+
 def main():
     B = len(SIZES)
     army, owner, typ, ws, hs, ps = H.gen_boards(SEED, SIZES, MAX_W, MAX_H)
@@ -91,6 +134,7 @@ def main():
            "sizes": SIZES, "max": [MAX_W, MAX_H, MAX_P], "seed": SEED, "warm_turns": WARM_TURNS, "record_turns": RECORD_TURNS,
            "boards": {"army": army.tolist(), "owner": owner.tolist(), "type": typ.tolist()},
            "turn_actions": turns, "expected": expected}
+    out["client_flow"] = client_flow()
     path = os.path.join(HERE, "stream_client_fixtures.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
