@@ -177,3 +177,114 @@ class GeneralsVecEnv:
 
     def close(self):
         self.engine.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The single-env shape: what code written against the reference's `GeneralsEnv` (and its ParallelEnvPool, whose
+# env_factory makes one env per worker) instantiates.  gymnasium is not a dependency of this package: the two spaces are
+# minimal stand-ins with the attributes that code reads (.shape / .dtype / .low / .high, .n / .sample() / .contains()).
+# --------------------------------------------------------------------------------------------------------------------
+class _Box:
+    def __init__(self, low, high, shape, dtype):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool((x >= self.low).all() and (x <= self.high).all())
+
+
+class _Discrete:
+    def __init__(self, n, seed=None):
+        self.n = int(n)
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self, mask=None):
+        if mask is not None and np.any(mask):
+            return int(self._rng.choice(np.flatnonzero(mask)))
+        return int(self._rng.integers(self.n))
+
+    def contains(self, x):
+        return 0 <= int(x) < self.n
+
+
+class GeneralsEnv:
+    """python/generals_gym/generals_env.py:GeneralsEnv - same constructor keywords, `observation_space` (Box(0, 1,
+    (9, H, W), float32), :111-116), `action_space` (Discrete(board_size * 5), :118-120), `reset(seed, options) -> (obs,
+    info)` (:142-208: info keys game_id / player_id / valid_actions_mask / turn), `step(action) -> (obs, reward, terminated,
+    truncated, info)` (:210-289: an action the mask rejects returns (obs, -0.1, False, False, {"invalid_action": True}) and
+    the game does not advance; otherwise info carries turn / valid_actions_mask / game_status / winner), `render`, `close` -
+    served by a ONE-board GeneralsVecEnv instead of a gRPC server (`server_address` is kept as an attribute only).  One board
+    per launch wastes the GPU: use GeneralsVecEnv / ParallelVecEnvPool for throughput; this class is for code that wants the
+    reference's object.  Opponent: the on-device random agent (the reference's default is a random opponent too, :443-497;
+    a custom `opponent_agent` needs the proto GameState and is not supported)."""
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
+
+    def __init__(self, server_address="localhost:50051", board_width=15, board_height=15, max_players=2, fog_of_war=True,
+                 render_mode=None, self_play=False, opponent_agent=None, max_turns=500, turn_time_ms=500,
+                 collect_experiences=False, device=0, seed=0):
+        if opponent_agent is not None or self_play:
+            raise NotImplementedError("opponent_agent / self_play act on the proto GameState of a gRPC server; opponents here are the on-device random agent")
+        self.server_address, self.board_width, self.board_height = server_address, board_width, board_height
+        self.board_size = board_width * board_height
+        self.max_players, self.fog_of_war, self.render_mode = max_players, fog_of_war, render_mode
+        self.self_play, self.opponent_agent, self.max_turns = self_play, opponent_agent, max_turns
+        self.turn_time_ms, self.collect_experiences = turn_time_ms, collect_experiences
+        self._vec = GeneralsVecEnv(1, board_width, board_height, max_players, fog_of_war=fog_of_war, max_turns=max_turns, seed=seed,
+                                   device=device, board_pool=4)
+        self._seed, self._games = seed, 0
+        self.game_id = None
+        self.player_id = None
+        self.turn_count = 0
+        self.observation_space = _Box(0.0, 1.0, (9, board_height, board_width), np.float32)
+        self.action_space = _Discrete(self.board_size * 5, seed)
+        self.valid_actions_mask = None
+        self._obs = None
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self._seed = seed
+        self._games += 1
+        obs, info = self._vec.reset(seed=self._seed * 7919 + self._games)      # a new game (CreateGame + JoinGame x2, :158-186)
+        self.game_id, self.player_id, self.turn_count = f"vec-game-{self._games}", 0, 0
+        self._obs = obs[0].copy()
+        self.valid_actions_mask = info["valid_actions_mask"][0].copy()
+        return self._obs, {"game_id": self.game_id, "player_id": self.player_id, "valid_actions_mask": self.valid_actions_mask,
+                           "turn": self.turn_count}
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self._vec.step(np.array([int(action)], np.int64))
+        self._obs = obs[0].copy()
+        if info["invalid_action"][0]:                                           # :226-231
+            return self._obs, -0.1, False, False, {"invalid_action": True}
+        if info["error"][0]:                                                    # :240-243: the server refused the move
+            return self._obs, -0.1, False, False, {"error": "move rejected by the engine"}
+        self.turn_count = int(info["turn"][0])
+        self.valid_actions_mask = info["valid_actions_mask"][0].copy()
+        term, trunc = bool(terminated[0]), bool(truncated[0])
+        return self._obs, float(reward[0]), term, trunc, {
+            "turn": self.turn_count, "valid_actions_mask": self.valid_actions_mask,
+            "game_status": "GAME_STATUS_FINISHED" if term else "GAME_STATUS_IN_PROGRESS",      # common.proto:60-64
+            "winner": int(info["winner"][0]) if term else None}
+
+    def render(self):
+        if self.render_mode == "human" and self._obs is not None:               # :563-597, from the observation channels
+            o = self._obs
+            print(f"\nTurn {self.turn_count}")
+            for y in range(self.board_height):
+                row = "|"
+                for x in range(self.board_width):
+                    if not o[0, y, x]:
+                        cell = " ? "
+                    elif o[4, y, x]:
+                        cell = "###"
+                    elif o[1, y, x] == 0.5:
+                        cell = f" {int(round(float(np.exp(o[2, y, x] * 10.0)) - 1)):2}"
+                    elif o[1, y, x] == 1.0:
+                        cell = f"-{int(round(float(np.exp(o[2, y, x] * 10.0)) - 1)):2}"
+                    else:
+                        cell = " . "
+                    row += cell + "|"
+                print(row)
+
+    def close(self):
+        self._vec.close()

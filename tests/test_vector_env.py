@@ -490,3 +490,39 @@ def test_gym_step_equals_the_four_call_composition(w, h, P, fog):
         four.resetting.copy_(four.out["needs_reset"])
     assert seen["trunc"] > 0 and seen["invalid"] > 0 and seen["reset"] > 0
     H.assert_states_equal(one.e.game_state(), four.e.game_state(), "gym_step vs composition")
+
+
+@pytest.mark.gpu
+def test_single_env_facade_has_the_reference_env_s_shape():
+    """GeneralsEnv (the single-env object code written for the reference instantiates): constructor keywords, spaces,
+    reset / step tuples and info keys of generals_env.py:48-289; an episode loop like python/test_gym_env.py's; and the
+    REFERENCE-shaped env_factory(worker_id) of ParallelEnvPool driving it unchanged through this package's pool in its
+    per-worker form."""
+    from generalsreinforcementlearning_amd.vector_env import GeneralsEnv
+    env = GeneralsEnv(server_address="localhost:50051", board_width=6, board_height=5, max_players=2, fog_of_war=False, max_turns=30)
+    assert env.observation_space.shape == (9, 5, 6) and env.observation_space.dtype == np.float32 and env.action_space.n == 150
+    obs, info = env.reset()
+    assert obs.shape == (9, 5, 6) and obs.dtype == np.float32 and env.observation_space.contains(obs)
+    assert set(info) == {"game_id", "player_id", "valid_actions_mask", "turn"} and info["turn"] == 0 and info["valid_actions_mask"].shape == (150,)
+    mask = info["valid_actions_mask"]
+    o2, r, term, trunc, inf = env.step(int(np.flatnonzero(~mask)[0]))                    # an action the mask rejects
+    assert (r, term, trunc, inf) == (-0.1, False, False, {"invalid_action": True}) and np.array_equal(o2, obs)
+    steps, ended = 0, False
+    for episode in range(3):
+        obs, info = env.reset()
+        for _ in range(40):
+            a = env.action_space.sample(info["valid_actions_mask"])
+            obs, r, term, trunc, info = env.step(a)
+            steps += 1
+            assert isinstance(r, float) and isinstance(term, bool) and isinstance(trunc, bool)
+            assert set(info) == {"turn", "valid_actions_mask", "game_status", "winner"}
+            assert info["game_status"] == ("GAME_STATUS_FINISHED" if term else "GAME_STATUS_IN_PROGRESS") and (info["winner"] is None) == (not term)
+            if term or trunc:
+                ended = True
+                assert trunc == (info["turn"] >= 30) or term
+                break
+    assert ended and steps > 30
+    env.render()
+    env.close()
+    with pytest.raises(NotImplementedError):
+        GeneralsEnv(opponent_agent=object())
