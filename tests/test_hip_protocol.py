@@ -10,6 +10,9 @@ with its own agent and pool (same counter RNG, keyed by env id):
                                          and every 5 turns for seeds 2, 3 (SURVEY asks every 25); seed 1 also checks
                                          fused == per-turn over all 262,144 envs
 
+  configs[4]  12,288 mixed boards: env i is 10x10 / 15x15 / 20x20 with 2 + i % 3 players, padded to 20x20 4P, its start turn
+              offset by i % 25 (growth turns diverge), 10 permille invalid moves, a mixed-size pool - ALL envs every 5 turns
+
 "Compared" = H.assert_states_equal: every tile plane (army, owner, type, visible, listed, changed, vis_changed), turn,
 done, winner, sizes, alive / army_count / tile_count per player, general_idx by contract.  All through the C ABI."""
 import os
@@ -108,4 +111,30 @@ def test_config3_262144x20x20_4p_subset_every_turn_or_5(g, seed):
     del bits
     if seed == 1:
         _fused_equals_per_turn(g, eng, B, w, h, p, True, seed, 5, pool=4096)
+    eng.close()
+
+
+def test_config4_mixed_padded_batch_with_turn_offsets(g):
+    """SURVEY 8(d) item 5 / BASELINE configs[4] at protocol length: one padded batch of three board sizes and player counts,
+    per-env turn counters offset so that the every-25th-turn growth hits different envs on different launches."""
+    B, seed = 12288, 1
+    side = np.array([10, 15, 20], np.int32)
+    ws = side[np.arange(B) % 3]
+    ps = (2 + np.arange(B) % 3).astype(np.int32)
+    eng = g.VecEngine(B, 20, 20, 4, fog_of_war=True, auto_reset=True)
+    eng.reset_generated(1000 + seed, ws, ws, ps)
+    pool = 768
+    pw, pp = side[np.arange(pool) % 3], (2 + np.arange(pool) % 3).astype(np.int32)
+    eng.build_board_pool(pool, 7000 + seed, pw, pw, pp)
+    first = eng.game_state()
+    assert np.array_equal(first["width"], ws) and np.array_equal(first["players"], ps)
+    ora = O.OracleBatch(B, 20, 20, 4, fog=True)
+    ora.reset(first["army"], first["owner"], first["type"], first["width"], first["height"], first["players"])
+    ora.set_pool(pool, 7000 + seed, pw, pw, pp)
+    t0 = (np.arange(B) % 25).astype(np.int32)
+    eng.write_state({"turn": t0})
+    ora.write_state({"turn": t0})
+    H.assert_states_equal(eng.game_state(), ora.read_state(), "configs[4] after reset")
+    c = _lockstep(eng, ora, B, seed, permille=10, every=5, mask_every=100, ctx="configs[4]")
+    assert c["games_finished"] > 0, "no game finished: the mixed pool was never dealt"
     eng.close()
