@@ -388,10 +388,24 @@ def main():
         pw, pp = side[np.arange(args.pool) % 3], (2 + np.arange(args.pool) % 3).astype(np.int32)
         eng.build_board_pool(args.pool, args.seed * 7919 + rank, np.minimum(pw, min(W, H)), np.minimum(pw, min(W, H)), np.minimum(pp, P))
     else:
+        # "reset cost reported separately" - map generation (one thread per board), import into the resident
+        # layout and performInitialSetup for all B boards, and the auto-reset pool; outside the timed region
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
         eng.reset_generated(args.seed * 1000003 + rank)
+        eng.synchronize()
+        tr1 = time.perf_counter()
         eng.build_board_pool(args.pool, args.seed * 7919 + rank)
+        eng.synchronize()
+        tr2 = time.perf_counter()
+        reset_cost = {"reset_generated_ms": (tr1 - tr0) * 1e3, "boards": B, "boards_per_s": B / (tr1 - tr0),
+                      "pool_build_ms": (tr2 - tr1) * 1e3, "pool_boards": args.pool,
+                      "note": "gvec_reset_generated = on-device map generator + import + performInitialSetup (full stats, full fog, game-over "
+                              "check) for every board; a finished board re-dealt from the pool costs its step nothing extra (it replaces the turn)"}
     seed = args.seed
 
+    if args.mixed:
+        reset_cost = None
     rgs, side, slab_free = None, None, None
     if dist is not None and args.gather_envs > 0:
         # the one real exchange step of the path: compact EXPERIENCE RECORDS -> rank 0 (the StreamAggregator side,
@@ -601,6 +615,8 @@ def main():
                                  "float4 copy reaches on this part; traffic*: PMC-measured HBM bytes of this build; contract_*: SURVEY 8(d)'s "
                                  "7,280-B algorithmic figure (int32 armies, lists always stored), which this kernel undercuts - it can pass 1"},
         }
+        if reset_cost:
+            out["reset_cost"] = reset_cost
         if same_dev:
             out["rehearsal_same_device"] = True   # N ranks on ONE GPU over gloo: a choreography check, not a measurement
         if gathered:
