@@ -9,7 +9,7 @@
 int main(void) {
   const int B = 96, MW = 20, MH = 20, MP = 4;
   const int sizes[3][3] = {{10, 10, 2}, {15, 15, 3}, {20, 20, 4}};
-  int stride = MW * MH;
+  int stride = MW * MH;   /* B * stride >= 25 * 25: the Go-generator block below reuses the first board's planes */
   int32_t* army = calloc((size_t)B * stride, 4);
   int8_t* owner = malloc((size_t)B * stride);
   uint8_t* type = calloc((size_t)B * stride, 1);
@@ -25,7 +25,7 @@ int main(void) {
   ora_batch_set_pool(b, 11, 5, NULL, NULL, NULL);
   ora_action8* acts = calloc((size_t)B * MP, sizeof(ora_action8));
   int32_t* err = calloc(B, 4);
-  int mask_bytes = (((stride + 1) / 2) + 15) / 16 * 16;
+  int mask_bytes = ora_mask_bytes(stride);
   uint8_t* bits = malloc((size_t)B * MP * mask_bytes);
   float* rew = malloc(sizeof(float) * B * MP);
   float* obs = malloc(sizeof(float) * (size_t)B * 9 * stride);
@@ -40,6 +40,21 @@ int main(void) {
     for (int i = 0; i < B; i++) errs += err[i] != 0;
   }
   long long steps = ora_batch_rollout(b, 100, 9, 5, 1);
+  steps += ora_batch_rollout_masks(b, 60, 10, 5, 1, bits);   /* bits: [B][MP][ora_mask_bytes(stride)] */
+  /* Go's math/rand and the generator on it: default and custom configs, awkward seeds */
+  {
+    const int64_t seeds[] = {0, 1, -3, 12345, 2147483647LL, 2147483648LL, (int64_t)1 << 40};
+    const int32_t custom[7] = {10, 4, 8, 30, 35, 6, 7};
+    for (unsigned i = 0; i < sizeof seeds / sizeof seeds[0]; i++) {
+      if (ora_mapgen_go(seeds[i], 20, 20, 4, NULL, army, owner, type)) return 4;
+      if (ora_mapgen_go(seeds[i], 25, 25, 4, custom, army, owner, type)) return 6;
+      ora_gorand* r = ora_gorand_new(seeds[i]);
+      long long acc = 0;
+      for (int k = 0; k < 2000; k++) acc += ora_gorand_intn(r, 1 + (k % 97)) + (ora_gorand_int63(r) & 1);
+      ora_gorand_free(r);
+      if (acc < 0) return 5;
+    }
+  }
   printf("oracle sanitizer run OK: %lld aborted turns, %lld rollout steps\n", errs, steps);
   ora_batch_free(b);
   free(army); free(owner); free(type); free(acts); free(err); free(bits); free(rew); free(obs); free(done);
