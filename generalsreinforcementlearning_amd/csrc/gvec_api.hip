@@ -380,6 +380,13 @@ int32_t fan(gvec_handle* h, F f) {
   return rc;
 }
 
+// the ordinal of the shard that starts at env `begin` (a handful of shards: linear search)
+int ordinal_of(const gvec_handle* h, int begin) {
+  for (size_t k = 0; k < h->shards.size(); ++k)
+    if (h->shards[k]->begin == begin) return (int)k;
+  return 0;
+}
+
 int32_t host_only(int32_t mem, const char* what) {
   if (mem == GVEC_MEM_HOST) return GVEC_OK;
   set_err("%s with device pointers on a sharded handle: device memory belongs to one device - call it on gvec_shard(h, i)", what);
@@ -444,10 +451,8 @@ int32_t reset(gvec_handle* h, const int32_t* env_ids, int32_t n, const int32_t* 
     P.owner.insert(P.owner.end(), owner + i * st, owner + (i + 1) * st);
     P.type.insert(P.type.end(), type + i * st, type + (i + 1) * st);
   }
-  std::vector<int> index_of(h->cfg.num_envs + 1, 0);
-  for (size_t k = 0; k < h->shards.size(); ++k) index_of[h->shards[k]->begin] = (int)k;
-  return fan(h, [parts, index_of](gvec_handle* c, int begin, int) -> int32_t {
-    const Part& P = (*parts)[index_of[begin]];
+  return fan(h, [parts, h](gvec_handle* c, int begin, int) -> int32_t {
+    const Part& P = (*parts)[ordinal_of(h, begin)];
     if (P.ids.empty()) return GVEC_OK;
     return gvec_reset(c, P.ids.data(), (int32_t)P.ids.size(), P.army.data(), P.owner.data(), P.type.data(), P.w.data(), P.hh.data(), P.p.data(),
                       GVEC_MEM_HOST);
@@ -463,14 +468,12 @@ int32_t gather_records(gvec_handle* h, int32_t local_begin, int32_t n, int32_t e
     }
   if (n == 0) return GVEC_OK;
   const size_t rec = (size_t)gvec_experience_record_bytes(h);
-  std::vector<int> index_of(h->cfg.num_envs + 1, 0);
-  for (size_t k = 0; k < h->shards.size(); ++k) index_of[h->shards[k]->begin] = (int)k;
   return fan(h, [=](gvec_handle* c, int begin, int) -> int32_t {
     HIPCHK(hipSetDevice(c->cfg.device));
     DevBuf stage(c, gvec_handle::kStageSlots - 1);
     HIPCHK(stage.alloc((size_t)n * rec));
     RET_IF(gvec_experience_records(c, nullptr, GVEC_MEM_DEVICE, local_begin, n, env_id_base + begin, stage.p));
-    char* to = reinterpret_cast<char*>(dst) + (size_t)index_of[begin] * n * rec;
+    char* to = reinterpret_cast<char*>(dst) + (size_t)ordinal_of(h, begin) * n * rec;
     if (mem == GVEC_MEM_HOST) HIPCHK(hipMemcpyAsync(to, stage.p, (size_t)n * rec, hipMemcpyDeviceToHost, c->stream));
     else if (dst_device == c->cfg.device) HIPCHK(hipMemcpyAsync(to, stage.p, (size_t)n * rec, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(hipMemcpyPeerAsync(to, dst_device, stage.p, c->cfg.device, (size_t)n * rec, c->stream));   // over xGMI
@@ -1031,17 +1034,17 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
                      gvec_rollout_stats* stats) {
   if (!h || turns < 0) return GVEC_E_INVALID;
   if (h->sharded()) {
-    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->cfg.num_envs + 1);   // indexed by the shard's first env
+    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->shards.size());   // one per shard
     const bool want = stats != nullptr;
     const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int begin, int) {
-      return gvec_rollout(c, turns, seed, invalid_permille, fused, want ? &(*per)[begin] : nullptr);
+      return gvec_rollout(c, turns, seed, invalid_permille, fused, want ? &(*per)[sharded::ordinal_of(h, begin)] : nullptr);
     });
     if (stats) {
       memset(stats, 0, sizeof *stats);
-      for (auto& w : h->shards) {
-        stats->env_steps += (*per)[w->begin].env_steps;
-        stats->aborted_turns += (*per)[w->begin].aborted_turns;
-        stats->games_finished += (*per)[w->begin].games_finished;
+      for (const gvec_rollout_stats& p : *per) {
+        stats->env_steps += p.env_steps;
+        stats->aborted_turns += p.aborted_turns;
+        stats->games_finished += p.games_finished;
       }
     }
     return rc;
@@ -1098,13 +1101,13 @@ int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_
 int32_t gvec_counters(gvec_handle* h, gvec_rollout_stats* out) {
   if (!h || !out) return GVEC_E_INVALID;
   if (h->sharded()) {
-    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->cfg.num_envs + 1);
-    const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_counters(c, &(*per)[begin]); });
+    auto per = std::make_shared<std::vector<gvec_rollout_stats>>(h->shards.size());
+    const int32_t rc = sharded::fan(h, [=](gvec_handle* c, int begin, int) { return gvec_counters(c, &(*per)[sharded::ordinal_of(h, begin)]); });
     memset(out, 0, sizeof *out);
-    for (auto& w : h->shards) {
-      out->env_steps += (*per)[w->begin].env_steps;
-      out->aborted_turns += (*per)[w->begin].aborted_turns;
-      out->games_finished += (*per)[w->begin].games_finished;
+    for (const gvec_rollout_stats& p : *per) {
+      out->env_steps += p.env_steps;
+      out->aborted_turns += p.aborted_turns;
+      out->games_finished += p.games_finished;
     }
     return rc;
   }
