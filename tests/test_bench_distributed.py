@@ -93,3 +93,26 @@ def test_bench_plain_command_line_propagates_a_rank_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
                         "--envs-per-gpu", "64", "--rehearse-cpu"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
     assert r.returncode != 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_real_engines_on_one_gpu():
+    """The N > 1 choreography with REAL engines (own ranks, env-sharded boards, record kernels on every K-th step, gather,
+    GPU-side expansion on rank 0, played-turn counters summed over ranks): two ranks share this box's one GPU
+    (GVEC_BENCH_SAME_DEVICE=1: gloo carries what RCCL would - RCCL refuses two ranks on one device).  A choreography
+    check, not a measurement: the line says so."""
+    env = dict(_plain_env(), GVEC_BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+                        "--envs-per-gpu", "8192", "--gather-envs", "512", "--gather-every", "3", "--pool", "256", "--prewarm-s", "0.05",
+                        "--no-cpu-baseline", "--no-fused"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line, nothing else reaches stdout
+    d = json.loads(lines[0])
+    assert d["rehearsal_same_device"] is True and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_envs"] == 16384
+    assert d["board_launches"] == 16384 * 12 and 0.99 * d["board_launches"] <= d["env_steps_played"] <= d["board_launches"]
+    g_ = d["experience_gather"]
+    assert g_["ranks_seen"] == [0, 1] and g_["records_per_rank_per_gather"] == 512 and g_["experiences_decoded_last_step"] > 512
