@@ -45,6 +45,8 @@ SYMBOLS = {
     "gvec_set_stream": (_i32, [_vp, _vp]),
     "gvec_synchronize": (_i32, [_vp]),
     "gvec_last_error": (C.c_char_p, []),
+    "gvec_host_alloc": (_i32, [_u64, C.POINTER(_vp)]),
+    "gvec_host_free": (_i32, [_vp]),
     "gvec_num_envs": (_i32, [_vp]),
     "gvec_tile_stride": (_i32, [_vp]),
     "gvec_mask_bytes": (_i32, [_vp]),

@@ -690,6 +690,19 @@ int32_t gvec_synchronize(gvec_handle* h) {
   return GVEC_OK;
 }
 
+int32_t gvec_host_alloc(uint64_t bytes, void** out) {
+  if (!out || bytes == 0) return GVEC_E_INVALID;
+  *out = nullptr;
+  RET_IF(ensure_device());
+  HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return GVEC_OK;
+}
+int32_t gvec_host_free(void* p) {
+  if (!p) return GVEC_OK;
+  HIPCHK(hipHostFree(p));
+  return GVEC_OK;
+}
+
 int32_t gvec_num_envs(const gvec_handle* h) { return h ? h->cfg.num_envs : GVEC_E_INVALID; }
 int32_t gvec_tile_stride(const gvec_handle* h) { return h ? h->stride : GVEC_E_INVALID; }
 int32_t gvec_mask_bytes(const gvec_handle* h) { return h ? h->mask_bytes : GVEC_E_INVALID; }

@@ -184,6 +184,13 @@ int32_t gvec_set_stream(gvec_handle* h, void* hip_stream);
 int32_t gvec_synchronize(gvec_handle* h);
 const char* gvec_last_error(void);
 
+/* Page-locked host memory for the GVEC_MEM_HOST entry points: buffers obtained here are copied to / from the device at full
+ * PCIe rate (a pageable buffer - a Go slice, a numpy array - goes through the driver's bounce buffers at a fraction of
+ * it: 218 MB of legal masks per step at 262,144 boards take 18 ms pageable, 4 ms pinned).  Any host pointer is accepted by
+ * every entry point; these are simply faster.  A cgo host passes them as unsafe.Pointer / slices over C memory. */
+int32_t gvec_host_alloc(uint64_t bytes, void** out);
+int32_t gvec_host_free(void* p);
+
 /* sizes */
 int32_t gvec_num_envs(const gvec_handle* h);
 int32_t gvec_tile_stride(const gvec_handle* h);   /* max_width*max_height              */

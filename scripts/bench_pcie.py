@@ -13,3 +13,13 @@ for want_mask in (False, True):
         eng.step(acts, want_mask=want_mask)
     dt = (time.perf_counter() - t0) / n
     print(f"host-buffer gvec_step want_mask={want_mask}: {dt*1e3:.2f} ms/step -> {B/dt/1e6:.1f} M env-steps/s (PCIe-inclusive, pageable numpy buffers)")
+pacts = eng.pinned(acts.shape, acts.dtype)
+pacts[...] = acts
+for want_mask in (False, True):
+    eng.step(pacts, want_mask=want_mask, pinned=True)
+    t0 = time.perf_counter(); n = 5
+    for _ in range(n):
+        eng.step(pacts, want_mask=want_mask, pinned=True)
+    dt = (time.perf_counter() - t0) / n
+    print(f"host-buffer gvec_step want_mask={want_mask}: {dt*1e3:.2f} ms/step -> {B/dt/1e6:.1f} M env-steps/s (PCIe-inclusive, PINNED buffers from gvec_host_alloc)")
+

@@ -214,3 +214,23 @@ def test_device_side_env_ids_are_range_checked(g):
     ids_ok = t(np.array([1, 4, 15], np.int32))
     check(eng.L.gvec_reset(eng.h, ids_ok.data_ptr(), n, *[x.data_ptr() for x in d], 1), "gvec_reset")
     assert (eng.game_state()["turn"][[1, 4, 15]] == 0).all()
+
+
+def test_pinned_host_buffers_give_the_same_results(g):
+    """gvec_host_alloc / VecEngine.pinned / step(pinned=True): page-locked buffers are only a faster road for the same bytes."""
+    B = 512
+    a, b = g.VecEngine(B, 12, 12, 3), g.VecEngine(B, 12, 12, 3)
+    for e in (a, b):
+        e.reset_generated(4)
+    pacts = b.pinned((B, 3), g.ACTION_DTYPE)
+    for k in range(25):
+        acts = a.agent_actions(9, 8)
+        pacts[...] = acts
+        e1, m1 = a.step(acts, want_mask=True)
+        e2, m2 = b.step(pacts, want_mask=True, pinned=True)
+        assert np.array_equal(e1, e2) and np.array_equal(m1, m2), k
+        assert np.array_equal(a.step(acts), b.step(pacts, pinned=True))
+    sa, sb = a.game_state(), b.game_state()
+    assert all(np.array_equal(sa[f], sb[f]) for f in sa)
+    b.close()
+    a.close()
