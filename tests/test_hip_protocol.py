@@ -25,7 +25,7 @@ import _oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = (1, 2, 3)
+SEEDS = tuple(int(v) for v in os.environ.get("GVEC_PROTOCOL_SEEDS", "1,2,3").split(","))   # the protocol's seeds; more for a manual soak
 TURNS = 500
 THREADS = max(1, min(16, os.cpu_count() or 1))
 
@@ -114,10 +114,11 @@ def test_config3_262144x20x20_4p_subset_every_turn_or_5(g, seed):
     eng.close()
 
 
-def test_config4_mixed_padded_batch_with_turn_offsets(g):
+@pytest.mark.parametrize("seed", SEEDS[:1] if len(SEEDS) <= 3 else SEEDS)
+def test_config4_mixed_padded_batch_with_turn_offsets(g, seed):
     """SURVEY 8(d) item 5 / BASELINE configs[4] at protocol length: one padded batch of three board sizes and player counts,
     per-env turn counters offset so that the every-25th-turn growth hits different envs on different launches."""
-    B, seed = 12288, 1
+    B = 12288
     side = np.array([10, 15, 20], np.int32)
     ws = side[np.arange(B) % 3]
     ps = (2 + np.arange(B) % 3).astype(np.int32)
