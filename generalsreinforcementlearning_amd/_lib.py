@@ -82,6 +82,7 @@ SYMBOLS = {
     "gvec_export_records": (_i32, [_vp, _i32, _i32, _vp]),
     "gvec_import_records": (_i32, [_vp, _i32, _i32, _vp]),
     "gvec_device_buffer": (_vp, [_vp, _i32]),
+    "gvec_read_buffer": (_i32, [_vp, _i32, _u64, _u64, _vp]),
     "gvec_selftest": (_i32, [_i32]),
 }
 

@@ -1079,7 +1079,10 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
     if (!h->legal_valid) RET_IF(refresh_legal(h));  // the per-turn agent samples from the mask buffer
     a.turns = 1;
     a.flags |= KF_LMVALID;
-    if (h->record_actions) a.actions_out = h->d_actions;  // gvec_record_agent_actions: what the agent played
+    if (h->record_actions) {  // gvec_record_agent_actions: what the agent played, and what the engine said to it
+      a.actions_out = h->d_actions;
+      a.err = h->d_err;
+    }
     for (int k = 0; k < turns; ++k) HIPCHK(launch_step(h->var, a, h->stream));
   }
   if (turns > 0) h->legal_valid = true;
@@ -1530,6 +1533,29 @@ int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n, const 
   h->legal_valid = false;
   // every record's header was checked on the device before anything was taken from it
   return check_status(h, "gvec_import_records");
+}
+
+int32_t gvec_read_buffer(gvec_handle* h, int32_t which, uint64_t byte_offset, uint64_t bytes, void* host_dst) {
+  if (!h || !host_dst) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_read_buffer");
+  const size_t B = (size_t)h->cfg.num_envs;
+  size_t total = 0;
+  const void* base = nullptr;
+  switch (which) {
+    case GVEC_BUF_HEADER: base = h->d_hdr; total = B * HDR_DW * 4; break;
+    case GVEC_BUF_LEGAL: base = h->d_legal; total = B * h->maxp * h->mask_bytes; break;
+    case GVEC_BUF_ACTIONS: base = h->d_actions; total = B * h->maxp * sizeof(gvec_action); break;
+    case GVEC_BUF_ERR: base = h->d_err; total = B * 4; break;
+    default:
+      set_err("gvec_read_buffer: buffer %d is not one of header / legal masks / actions / err", which);
+      return GVEC_E_INVALID;
+  }
+  if (byte_offset > total || bytes > total - byte_offset) return GVEC_E_RANGE;
+  if (bytes == 0) return GVEC_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(host_dst, reinterpret_cast<const char*>(base) + byte_offset, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
 }
 
 void* gvec_device_buffer(gvec_handle* h, int32_t which) {

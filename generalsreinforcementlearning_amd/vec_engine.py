@@ -355,3 +355,19 @@ class VecEngine:
 
     def device_buffer(self, which):
         return self.L.gvec_device_buffer(self.h, which)
+
+    def recorded_actions(self, env_begin=0, n=None):
+        """[n][max_players] ACTION_DTYPE: what the device agent played in the last per-turn rollout launch
+        (record_agent_actions on)."""
+        n = self.B - env_begin if n is None else n
+        out = np.zeros((n, self.max_p), ACTION_DTYPE)
+        per = self.max_p * ACTION_DTYPE.itemsize
+        check(self.L.gvec_read_buffer(self.h, 4, env_begin * per, n * per, _ptr(out)), "gvec_read_buffer")
+        return out
+
+    def last_errors(self, env_begin=0, n=None):
+        """[n] int32: the per-env codes of the last host-mode step or recorded per-turn rollout launch."""
+        n = self.B - env_begin if n is None else n
+        out = np.zeros(n, np.int32)
+        check(self.L.gvec_read_buffer(self.h, 5, env_begin * 4, n * 4, _ptr(out)), "gvec_read_buffer")
+        return out

@@ -365,7 +365,8 @@ int32_t gvec_experience_records(gvec_handle* h, const gvec_action* actions, int3
  * Enqueued on hip_stream (may be NULL) of `device`; device pointers only.  experience.py: expand_records_device. */
 int32_t gvec_expand_experience_records(int32_t device, void* hip_stream, const int32_t* layout8, const void* records, int32_t n,
                                        float* state, float* next_state, uint8_t* action_mask, int32_t* meta);
-/* on != 0: per-turn rollouts (gvec_rollout fused = 0) store the agent's moves in the handle's action buffer. */
+/* on != 0: per-turn rollouts (gvec_rollout fused = 0) store the agent's moves in the handle's action buffer and the
+ * per-env error codes (the sentinel of the first failing move, 0, or GVEC_ERR_GAME_OVER) in its err buffer. */
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on);
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
@@ -442,6 +443,10 @@ int32_t gvec_import_records(gvec_handle* h, int32_t env_begin, int32_t n,
 #define GVEC_BUF_ERR     5
 #define GVEC_BUF_ARMY_WIDE 6
 void*   gvec_device_buffer(gvec_handle* h, int32_t which);
+/* A byte range of one of the handle's small per-env buffers - GVEC_BUF_HEADER, _LEGAL, _ACTIONS (what the device agent
+ * played, while gvec_record_agent_actions is on) or _ERR (the per-env codes of the last gvec_step in host mode or, while
+ * recording is on, of the last per-turn gvec_rollout launch) - copied to host memory; synchronises the handle's stream. */
+int32_t gvec_read_buffer(gvec_handle* h, int32_t which, uint64_t byte_offset, uint64_t bytes, void* host_dst);
 
 /* Runs the on-device self-test of the wave primitives (DPP shifts, scans,
  * bpermute); 0 = pass.  Used by smoke tests on new driver / hardware revisions. */

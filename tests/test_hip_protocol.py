@@ -13,7 +13,8 @@ with its own agent and pool (same counter RNG, keyed by env id):
   configs[4]  12,288 mixed boards: env i is 10x10 / 15x15 / 20x20 with 2 + i % 3 players, padded to 20x20 4P, its start turn
               offset by i % 25 (growth turns diverge), 10 permille invalid moves, a mixed-size pool - ALL envs every 5 turns
 
-"Compared" = H.assert_states_equal: every tile plane (army, owner, type, visible, listed, changed, vis_changed), turn,
+"Compared" = the per-env ERROR CODE of the turn (the sentinel of the first failing move, 0, or ErrGameOver), the moves the
+device agent played against the oracle agent's, and H.assert_states_equal: every tile plane (army, owner, type, visible, listed, changed, vis_changed), turn,
 done, winner, sizes, alive / army_count / tile_count per player, general_idx by contract.  All through the C ABI."""
 import os
 
@@ -50,14 +51,22 @@ def _pair(g, B, sub, w, h, p, fog, seed, pool):
 
 
 def _lockstep(eng, ora, sub, seed, permille, every, mask_every, ctx):
-    aborted = 0
+    """BASELINE.md's parity gate: state AND error code identical after every compared turn - and the moves the device
+    agent played are the oracle agent's."""
+    eng.record_agent_actions(True)          # the launch also stores the agent's moves and the per-env error codes
     for k in range(TURNS):
         eng.rollout(1, seed, permille, fused=False, want_stats=False)      # ONE step-kernel launch over all B envs
-        ora.rollout(1, seed, permille, threads=THREADS)
+        acts = ora.agent_actions(seed, permille, threads=THREADS)
+        err = ora.step(acts, threads=THREADS)
         if (k + 1) % every == 0 or k == TURNS - 1:
+            got_err = eng.last_errors(0, sub)
+            assert np.array_equal(got_err, err), (f"{ctx} seed {seed} turn {k + 1}: error codes differ in envs "
+                                                  f"{np.flatnonzero(got_err != err)[:8]}")
+            assert np.array_equal(eng.recorded_actions(0, sub), acts), f"{ctx} seed {seed} turn {k + 1}: agent moves differ"
             H.assert_states_equal(eng.game_state(0, sub), ora.read_state(), f"{ctx} seed {seed} after turn {k + 1}")
         if mask_every and ((k + 1) % mask_every == 0 or k == TURNS - 1):
             assert np.array_equal(eng.legal_action_mask_bits()[:sub], ora.legal_mask(threads=THREADS)), f"{ctx} seed {seed} masks after turn {k + 1}"
+    eng.record_agent_actions(False)
     c = eng.counters()
     assert c["aborted_turns"] > 0, "no turn was aborted: H5 was not exercised"
     return c
