@@ -1451,6 +1451,44 @@ int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const
   return GVEC_OK;
 }
 
+int32_t gvec_stream_delta_cap(const gvec_handle* h) { return h ? (h->stride / 5 > 1 ? h->stride / 5 : 1) : GVEC_E_INVALID; }
+
+int32_t gvec_stream_deltas(gvec_handle* h, int32_t player, uint8_t* kind, int32_t* count, uint64_t* updates, int32_t mem) {
+  if (!h || !kind || !count || !updates || player < 0 || player >= h->maxp) return GVEC_E_INVALID;
+  const int cap = gvec_stream_delta_cap(h);
+  if (h->sharded()) {
+    RET_IF(sharded::host_only(mem, "gvec_stream_deltas"));
+    return sharded::fan(h, [=](gvec_handle* c, int begin, int) {
+      return gvec_stream_deltas(c, player, kind + begin, count + begin, updates + (size_t)begin * cap, GVEC_MEM_HOST);
+    });
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->cfg.num_envs;
+  DevBuf bk(h, 0), bc(h, 1), bu(h, 2);
+  StreamDeltaArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
+  a.num_envs = h->cfg.num_envs;
+  a.fd = h->fd;
+  a.row_dw = h->row_dw;
+  a.player = player;
+  a.cap = cap;
+  unsigned long long* du = nullptr;
+  RET_IF(stage_out(bk, kind, B, mem, &a.kind));
+  RET_IF(stage_out(bc, count, B, mem, &a.count));
+  RET_IF(stage_out(bu, reinterpret_cast<unsigned long long*>(updates), B * cap, mem, &du));
+  a.updates = du;
+  HIPCHK(launch_stream_deltas(h->var, a, h->stream));
+  RET_IF(copy_out(h, bk, kind, B, mem));
+  RET_IF(copy_out(h, bc, count, B, mem));
+  RET_IF(copy_out(h, bu, reinterpret_cast<unsigned long long*>(updates), B * cap, mem));
+  if (mem == GVEC_MEM_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+  return GVEC_OK;
+}
+
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
   if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
   if (h->sharded()) {

@@ -1110,6 +1110,68 @@ __global__ void gym_actions_kernel(GymActArgs A) {
 }
 
 // =========================================================================================
+// gameInstance.createStreamUpdate's delta (internal/grpc/gameserver/server.go:636-777) for one player's stream, every env:
+// when 0 < |ChangedTiles| + |VisibilityChangedTiles| < N / 5 (a tile in both sets counts twice, :636-640) the update is a
+// GameStateDelta whose tile updates are the tiles of either set with the proto's fog rules applied for that player
+// (:664-689 == :556-582); otherwise the server sends the full state.  The handful of tiles a turn touches leave the GPU
+// instead of the board: ~10 eight-byte updates per env instead of 4 KB of planes.
+// updates[env][k] = tile index | type << 16 | visible << 18 | fog_of_war << 19 | (owner + 1) << 20 | army << 32, the changed
+// tiles ascending, then the visibility-only ones ascending (Go ranges over maps: its order is unspecified).
+// =========================================================================================
+template <int MAXP, int NSLOT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stream_delta_kernel(StreamDeltaArgs A) {
+  using B = Board<MAXP, NSLOT>;
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int env = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  if (env >= A.num_envs) return;
+  B b;
+  load_board(b, A.hdr + (size_t)env * HDR_DW, A.rows + (size_t)env * A.row_dw, army_cref<NSLOT>(A.army16, A.army32, env), A.fd);
+  const int nc = b.count(b.chg), nv = b.count(b.vch);
+  const int total = nc + nv;
+  const bool delta = total > 0 && total < b.N / 5;       // :640 (integer division)
+  if (lane == 0) {
+    A.kind[env] = (uint8_t)(delta ? 1 : 2);
+    A.count[env] = delta ? b.count(b.chg | b.vch) : 0;
+  }
+  if (!delta) return;                                     // wave-uniform
+  const bool fog_on = (b.hflags & HF_FOG) != 0u;
+  uint32_t vis_p = 0u;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) vis_p = (p == A.player) ? b.vis[p] : vis_p;
+  unsigned long long* out = A.updates + (size_t)env * A.cap;
+  int base = 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t sel_plane = pass == 0 ? b.chg : (b.vch & ~b.chg);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      int owner = -1;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) owner = b.gather(b.own[p], s) ? p : owner;
+      const uint32_t is_gen = b.gather(b.gen, s), is_city = b.gather(b.city, s), is_mtn = b.gather(b.mtn, s);
+      const uint32_t pv = b.gather(vis_p, s);
+      const bool sel = b.gather(sel_plane, s) != 0u && t < b.N;
+      int type = is_gen ? GVEC_TILE_GENERAL : (is_city ? GVEC_TILE_CITY : (is_mtn ? GVEC_TILE_MOUNTAIN : GVEC_TILE_NORMAL));
+      const bool visible = !fog_on || pv != 0u;                        // ComputePlayerVisibility (visibility_optimized.go:166-195)
+      const bool fogged = !visible && type != GVEC_TILE_NORMAL;
+      int32_t army = b.army[s];
+      if (!visible) {                                                  // :676-688: hidden or fogged - the current state is withheld
+        owner = -1;
+        army = 0;
+      }                                                                // (a hidden tile IS a normal tile: its type needs no rewrite)
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+      const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (sel && pos < A.cap)
+        out[pos] = (unsigned long long)((uint32_t)t | ((uint32_t)type << 16) | ((visible ? 1u : 0u) << 18) | ((fogged ? 1u : 0u) << 19) |
+                                        ((uint32_t)(owner + 1) << 20)) |
+                   ((unsigned long long)(uint32_t)army << 32);
+      base += __builtin_popcountll(m);
+    }
+  }
+}
+
+// =========================================================================================
 // import: planes -> resident record (gvec_reset / gvec_write_state / pool build)
 // =========================================================================================
 template <int MAXP, int NSLOT>
@@ -1793,6 +1855,12 @@ hipError_t launch_gym_step(const Variant& v, const StepArgs& in, const GymStepAr
     const dim3 grid = wave_grid(a.num_envs), block(64 * WAVES_PER_BLOCK);
     if (odd) hipLaunchKernelGGL((gym_step_kernel<P, S, true>), grid, block, 0, s, a, g);
     else hipLaunchKernelGGL((gym_step_kernel<P, S, false>), grid, block, 0, s, a, g);
+    return hipGetLastError();
+  });
+}
+hipError_t launch_stream_deltas(const Variant& v, const StreamDeltaArgs& a, hipStream_t s) {
+  return dispatch(v, [&](auto P_, auto S_) {
+    hipLaunchKernelGGL((stream_delta_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
 }

@@ -187,6 +187,18 @@ struct GymStepArgs {
   int32_t* prev_stats;         // [B][3*MAXP], as GymArgs
   int32_t stride, player, max_turns;
 };
+// gvec_stream_deltas: createStreamUpdate's delta for one player's stream (server.go:636-777)
+struct StreamDeltaArgs {
+  const uint32_t* hdr;
+  const uint32_t* rows;
+  const uint32_t* army16;
+  const int32_t* army32;
+  uint8_t* kind;                 // [B] 1 delta, 2 the server would send the full state
+  int32_t* count;                // [B] tile updates of the delta
+  unsigned long long* updates;   // [B][cap]
+  int32_t num_envs, fd, row_dw, player, cap;
+};
+hipError_t launch_stream_deltas(const Variant& v, const StreamDeltaArgs& a, hipStream_t s);
 // the consumer side of the record exchange: layout8 as gvec_experience_record_layout fills it
 hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* layout8, float* state, float* next_state, uint8_t* mask,
                                  int32_t* meta, hipStream_t s);

@@ -263,6 +263,16 @@ class VecEngine:
         check(self.L.gvec_player_visibility(self.h, player_id, _ptr(vis), _ptr(fog), MEM_HOST), "gvec_player_visibility")
         return vis.astype(bool), fog.astype(bool)
 
+    # ---- createStreamUpdate's deltas (server.go:632-777) -----------------------------------------
+    def stream_deltas(self, player):
+        """-> kind[B] (1 delta / 2 full state), count[B], updates[B][cap] uint64 (include/generals_vec.h gvec_stream_deltas):
+        what a turn's broadcast needs of the boards, a few bytes per env."""
+        cap = self.L.gvec_stream_delta_cap(self.h)
+        kind, count = np.zeros(self.B, np.uint8), np.zeros(self.B, np.int32)
+        upd = np.zeros((self.B, cap), np.uint64)
+        check(self.L.gvec_stream_deltas(self.h, player, _ptr(kind), _ptr(count), _ptr(upd), MEM_HOST), "gvec_stream_deltas")
+        return kind, count, upd
+
     # ---- synthetic random-agent rollouts ----------------------------------------------------------
     def set_agent_mix(self, noop_per_65536=6554, half_per_65536=19661):
         """Random-agent mix for rollout / agent_actions: P(no-op) = noop/65536, P(half move) = half/65536.

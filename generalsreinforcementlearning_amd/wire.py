@@ -214,6 +214,32 @@ def stream_update(st, vis, fog, legal_mask, e, viewer, game_id="", names=None):
     return up
 
 
+def stream_update_from_delta(st, kind, count, updates, e, viewer, names=None):
+    """The GameUpdate of env e from gvec_stream_deltas' outputs (VecEngine.stream_deltas(viewer)) and the per-player fields
+    of VecEngine.game_state: the delta itself, or None when the server would send the full state (kind 2: build it with
+    `game_state`).  Equal to `stream_update` message for message (tests/test_wire.py)."""
+    if int(kind[e]) != 1:
+        return None
+    w, P = int(st["width"][e]), int(st["players"][e])
+    names = names or [f"player{p}" for p in range(P)]
+    up = GameUpdate()
+    up.timestamp.GetCurrentTime()
+    d = up.delta
+    d.turn = int(st["turn"][e])
+    for u in updates[e, : int(count[e])]:
+        u = int(u)
+        t, typ, owner = u & 0xFFFF, (u >> 16) & 3, ((u >> 20) & 0xF) - 1
+        army = (u >> 32) & 0xFFFFFFFF
+        army = army - (1 << 32) if army >= 1 << 31 else army
+        tu = d.tile_updates.add()
+        tu.position.x, tu.position.y = t % w, t // w
+        tu.tile.CopyFrom(Tile(type=TILE_TYPE[typ], owner_id=owner, army_count=army, visible=bool((u >> 18) & 1), fog_of_war=bool((u >> 19) & 1)))
+    for p in range(P):
+        pu = d.player_updates.add(player_id=p)
+        pu.state.CopyFrom(_player_state(st, e, p, names[p], viewer, delta=True))
+    return up
+
+
 def experience(d, collector_version="1.0.0"):
     """One experience dict (VecExperienceCollector.as_dicts / decode_records) -> experiencepb.Experience as
     SimpleCollector.OnStateTransition fills it (collector.go:58-83)."""

@@ -371,6 +371,23 @@ int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on);
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem);
 int32_t gvec_serializer_mask(gvec_handle* h, uint8_t* bits, int32_t mem);
 
+/* ---- the gRPC surface's per-turn broadcast --------------------------------------------------
+ * gameInstance.createStreamUpdate (internal/grpc/gameserver/server.go:632-777) decides per env and player stream: when
+ * 0 < |ChangedTiles| + |VisibilityChangedTiles| < W*H/5 the update is a GameStateDelta - the tiles of either set with the
+ * proto's fog rules for that player (:664-689) plus every PlayerState - else the full GameState.  gvec_stream_deltas
+ * makes that decision and builds the delta's tile updates on the device, so that a turn's broadcast reads back a few
+ * eight-byte updates per env instead of the board:
+ *   kind[B]    1 = delta, 2 = the server sends convertGameStateToProto's full state (gvec_read_state + gvec_player_visibility)
+ *   count[B]   tile updates of the delta (0 for kind 2)
+ *   updates    [B][cap] uint64, cap = gvec_stream_delta_cap(h) (= max(1, tile_stride / 5): a delta has fewer than N/5):
+ *              bits 0-15 tile index y*W + x | 16-17 Tile.Type (core numbering, after the fog rules) | 18 visible |
+ *              19 fog_of_war | 20-23 owner + 1 (0: -1, i.e. neutral or withheld) | 32-63 army (int32, 0 when withheld);
+ *              the ChangedTiles in ascending order, then the tiles only in VisibilityChangedTiles (Go's map order is
+ *              unspecified).  PlayerUpdates come from gvec_read_state's per-player fields (a few bytes per env).
+ * GVEC_MEM_HOST or GVEC_MEM_DEVICE. */
+int32_t gvec_stream_delta_cap(const gvec_handle* h);
+int32_t gvec_stream_deltas(gvec_handle* h, int32_t player, uint8_t* kind, int32_t* count, uint64_t* updates, int32_t mem);
+
 /* ---- python/generals_gym on the device ------------------------------------------
  * What GeneralsEnv builds on the client from the GameState proto of its player token, computed straight
  * from the resident state with the proto's fog rules (server.go:556-582) applied in the kernel.  Every

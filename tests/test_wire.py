@@ -245,3 +245,50 @@ def test_hip_states_to_protos_equal_oracle_states_to_protos():
                         if s.HasField("general_position"):
                             s.general_position.x, s.general_position.y = 0, 0
                 assert a == b, (k, e, viewer)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fog", [True, False], ids=["fog_on", "fog_off"])
+def test_device_stream_deltas_equal_create_stream_update(fog):
+    """gvec_stream_deltas (the delta-vs-full decision of server.go:636-644 and the delta's tile updates, built on the
+    device) against wire.stream_update (the host restatement this file pins to the scalar createStreamUpdate): per env and
+    viewer the same decision, and for deltas the same GameUpdate message - over a padded mixed batch, every turn, with
+    aborted turns, eliminations and turns where nothing changed; and through a sharded handle."""
+    import generalsreinforcementlearning_amd as g
+    import _harness as H
+    B = 60
+    per = [[(10, 8, 3), (7, 7, 2), (12, 12, 4), (20, 20, 4)][i % 4] for i in range(B)]
+    army, owner, typ, ws, hs, ps = H.gen_boards(17, per, 20, 20)
+    eng = g.VecEngine(B, 20, 20, 4, fog_of_war=fog)
+    many = g.VecEngine(B, 20, 20, 4, fog_of_war=fog, devices=[0, 0, 0])
+    for e_ in (eng, many):
+        e_.reset(army, owner, typ, ws, hs, ps)
+    seen = {1: 0, 2: 0}
+    for k in range(70):
+        acts = eng.agent_actions(5, 15)
+        eng.step(acts)
+        many.step(acts)
+        st = eng.game_state(fields=wire.STATE_FIELDS)
+        for viewer in (0, 1, 3):
+            kind, count, upd = eng.stream_deltas(viewer)
+            k2, c2, u2 = many.stream_deltas(viewer)
+            assert np.array_equal(kind, k2) and np.array_equal(count, c2)
+            vis, fg = eng.compute_player_visibility(viewer)
+            for e in range(B):
+                w, h, P = per[e]
+                if viewer >= P:
+                    continue
+                assert np.array_equal(upd[e, : count[e]], u2[e, : count[e]])
+                want = wire.stream_update(st, vis, fg, np.zeros(w * h * 4, bool), e, viewer)
+                got = wire.stream_update_from_delta(st, kind, count, upd, e, viewer)
+                seen[int(kind[e])] += 1
+                if want.WhichOneof("update") == "full_state":
+                    assert kind[e] == 2 and got is None and count[e] == 0, (k, e, viewer)
+                else:
+                    assert kind[e] == 1 and got is not None, (k, e, viewer)
+                    want.ClearField("timestamp")
+                    got.ClearField("timestamp")
+                    assert got == want, (k, e, viewer)
+    assert seen[1] > 1000 and seen[2] > 50
+    eng.close()
+    many.close()
