@@ -1129,9 +1129,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stream_delta_kernel(Stre
   const int nc = b.count(b.chg), nv = b.count(b.vch);
   const int total = nc + nv;
   const bool delta = total > 0 && total < b.N / 5;       // :640 (integer division)
+  const int n_union = b.count(b.chg | b.vch);            // a wave-wide reduction: every lane takes part
   if (lane == 0) {
     A.kind[env] = (uint8_t)(delta ? 1 : 2);
-    A.count[env] = delta ? b.count(b.chg | b.vch) : 0;
+    A.count[env] = delta ? n_union : 0;
   }
   if (!delta) return;                                     // wave-uniform
   const bool fog_on = (b.hflags & HF_FOG) != 0u;

@@ -288,7 +288,11 @@ def test_device_stream_deltas_equal_create_stream_update(fog):
                     assert kind[e] == 1 and got is not None, (k, e, viewer)
                     want.ClearField("timestamp")
                     got.ClearField("timestamp")
-                    assert got == want, (k, e, viewer)
+                    if got != want:
+                        a_ = [(u.position.x, u.position.y, u.tile.type, u.tile.owner_id, u.tile.army_count, u.tile.visible, u.tile.fog_of_war) for u in got.delta.tile_updates]
+                        b_ = [(u.position.x, u.position.y, u.tile.type, u.tile.owner_id, u.tile.army_count, u.tile.visible, u.tile.fog_of_war) for u in want.delta.tile_updates]
+                        raise AssertionError((k, e, viewer, [x for x in zip(a_, b_) if x[0] != x[1]][:4], len(a_), len(b_),
+                                              str(got.delta.player_updates) == str(want.delta.player_updates)))
     assert seen[1] > 1000 and seen[2] > 50
     eng.close()
     many.close()
