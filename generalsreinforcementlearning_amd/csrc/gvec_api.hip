@@ -1489,6 +1489,51 @@ int32_t gvec_stream_deltas(gvec_handle* h, int32_t player, uint8_t* kind, int32_
   return GVEC_OK;
 }
 
+int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, uint8_t* kind, int64_t* offset, uint64_t* updates, int64_t capacity,
+                                  int64_t* total) {
+  if (!h || !kind || !offset || !updates || !total || capacity < 0 || player < 0 || player >= h->maxp) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_stream_deltas_packed");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int cap = gvec_stream_delta_cap(h);
+  const size_t B = (size_t)h->cfg.num_envs;
+  DevBuf bk(h, 0), bc(h, 1), bu(h, 2), bo(h, 3), bp(h, 4);
+  HIPCHK(bk.alloc(B));
+  HIPCHK(bc.alloc(B * 4));
+  HIPCHK(bu.alloc(B * cap * 8));
+  HIPCHK(bo.alloc((B + 1) * 8));
+  HIPCHK(bp.alloc(B * cap * 8));
+  StreamDeltaArgs a;
+  memset(&a, 0, sizeof a);
+  a.hdr = h->d_hdr;
+  a.rows = h->d_rows;
+  a.army16 = h->d_army16;
+  a.army32 = h->d_army32;
+  a.num_envs = h->cfg.num_envs;
+  a.fd = h->fd;
+  a.row_dw = h->row_dw;
+  a.player = player;
+  a.cap = cap;
+  a.kind = bk.as<uint8_t>();
+  a.count = bc.as<int32_t>();
+  a.updates = bu.as<unsigned long long>();
+  HIPCHK(launch_stream_deltas(h->var, a, h->stream));
+  HIPCHK(launch_pack_updates(bu.as<unsigned long long>(), bc.as<int32_t>(), bo.as<long long>(), bp.as<unsigned long long>(), h->cfg.num_envs, cap,
+                             (long long)(B * cap), h->stream));
+  HIPCHK(hipMemcpyAsync(kind, bk.p, B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(offset, bo.p, (B + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *total = offset[B];
+  if (*total > capacity) {
+    set_err("gvec_stream_deltas_packed: %lld updates, room for %lld", (long long)*total, (long long)capacity);
+    return GVEC_E_RANGE;
+  }
+  if (*total > 0) {
+    HIPCHK(hipMemcpyAsync(updates, bp.p, (size_t)*total * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return GVEC_OK;
+}
+
 int32_t gvec_observe(gvec_handle* h, int32_t player, float* out, int32_t mem) {
   if (!h || !out || player < -1 || player >= h->maxp) return GVEC_E_INVALID;
   if (h->sharded()) {

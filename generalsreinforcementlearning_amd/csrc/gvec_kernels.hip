@@ -1172,6 +1172,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stream_delta_kernel(Stre
   }
 }
 
+// gvec_stream_deltas_packed: exclusive prefix sum of the per-env update counts (one workgroup: B is a few hundred thousand
+// small integers) and the row-to-stream compaction that follows it.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* count, long long* offset, int32_t n) {
+  __shared__ long long part[1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+  long long sum = 0;
+  for (int i = lo; i < hi; ++i) sum += count[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1,024 partial sums
+    const long long add = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  long long run = part[tid] - sum;             // exclusive base of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    offset[i] = run;
+    run += count[i];
+  }
+  if (tid == 1023) offset[n] = part[1023];
+}
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pack_updates_kernel(const unsigned long long* rows, const int32_t* count, const long long* offset,
+                                                                            unsigned long long* packed, int32_t n, int32_t cap, long long capacity) {
+  const int env = (int)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (env >= n) return;
+  const long long base = offset[env];
+  const int c = count[env];
+  for (int k = lane_id(); k < c; k += 64)
+    if (base + k < capacity) packed[base + k] = rows[(size_t)env * cap + k];
+}
+
 // =========================================================================================
 // import: planes -> resident record (gvec_reset / gvec_write_state / pool build)
 // =========================================================================================
@@ -1864,6 +1898,12 @@ hipError_t launch_stream_deltas(const Variant& v, const StreamDeltaArgs& a, hipS
     hipLaunchKernelGGL((stream_delta_kernel<decltype(P_)::value, decltype(S_)::value>), wave_grid(a.num_envs), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     return hipGetLastError();
   });
+}
+hipError_t launch_pack_updates(const unsigned long long* rows, const int32_t* count, long long* offset, unsigned long long* packed, int32_t n,
+                               int32_t cap, long long capacity, hipStream_t s) {
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, count, offset, n);
+  hipLaunchKernelGGL(pack_updates_kernel, wave_grid(n), dim3(64 * WAVES_PER_BLOCK), 0, s, rows, count, offset, packed, n, cap, capacity);
+  return hipGetLastError();
 }
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gym_actions_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, s, a);

@@ -199,6 +199,9 @@ struct StreamDeltaArgs {
   int32_t num_envs, fd, row_dw, player, cap;
 };
 hipError_t launch_stream_deltas(const Variant& v, const StreamDeltaArgs& a, hipStream_t s);
+// offset[n + 1] = exclusive prefix sum of count[n]; packed[offset[e] + k] = rows[e][k] for k < count[e] (entries beyond `capacity` dropped)
+hipError_t launch_pack_updates(const unsigned long long* rows, const int32_t* count, long long* offset, unsigned long long* packed, int32_t n,
+                               int32_t cap, long long capacity, hipStream_t s);
 // the consumer side of the record exchange: layout8 as gvec_experience_record_layout fills it
 hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* layout8, float* state, float* next_state, uint8_t* mask,
                                  int32_t* meta, hipStream_t s);

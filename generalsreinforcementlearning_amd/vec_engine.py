@@ -273,6 +273,18 @@ class VecEngine:
         check(self.L.gvec_stream_deltas(self.h, player, _ptr(kind), _ptr(count), _ptr(upd), MEM_HOST), "gvec_stream_deltas")
         return kind, count, upd
 
+    def stream_deltas_packed(self, player):
+        """-> kind[B], offset[B + 1], updates[total]: env e's updates are updates[offset[e]:offset[e + 1]] - only the updates
+        that exist cross PCIe (gvec_stream_deltas_packed).  The landing buffers are page-locked and reused by the next call."""
+        cap = self.L.gvec_stream_delta_cap(self.h)
+        if not hasattr(self, "_sd"):
+            self._sd = (self.pinned((self.B,), np.uint8), self.pinned((self.B + 1,), np.int64), self.pinned((self.B * cap,), np.uint64))
+        kind, off, upd = self._sd
+        total = C.c_int64()
+        check(self.L.gvec_stream_deltas_packed(self.h, player, _ptr(kind), _ptr(off), _ptr(upd), self.B * cap, C.byref(total)),
+              "gvec_stream_deltas_packed")
+        return kind, off, upd[: total.value]
+
     # ---- synthetic random-agent rollouts ----------------------------------------------------------
     def set_agent_mix(self, noop_per_65536=6554, half_per_65536=19661):
         """Random-agent mix for rollout / agent_actions: P(no-op) = noop/65536, P(half move) = half/65536.

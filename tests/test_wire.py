@@ -271,6 +271,9 @@ def test_device_stream_deltas_equal_create_stream_update(fog):
         st = eng.game_state(fields=wire.STATE_FIELDS)
         for viewer in (0, 1, 3):
             kind, count, upd = eng.stream_deltas(viewer)
+            pk, poff, pupd = eng.stream_deltas_packed(viewer)         # the same updates as one stream
+            assert np.array_equal(pk, kind) and np.array_equal(np.diff(poff), count) and poff[0] == 0
+            assert np.array_equal(pupd, np.concatenate([upd[e_, : count[e_]] for e_ in range(B)]))
             k2, c2, u2 = many.stream_deltas(viewer)
             assert np.array_equal(kind, k2) and np.array_equal(count, c2)
             vis, fg = eng.compute_player_visibility(viewer)
