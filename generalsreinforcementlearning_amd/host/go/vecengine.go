@@ -300,3 +300,19 @@ func (e *VecEngine) GatherExperienceRecords(shardEnvBegin, n, envIDBase int) ([]
 	rc := C.gvec_gather_experience_records(e.h, C.int32_t(shardEnvBegin), C.int32_t(n), C.int32_t(envIDBase), C.GVEC_MEM_HOST, 0, unsafe.Pointer(&out[0]))
 	return out, apiErr(rc, "gvec_gather_experience_records")
 }
+
+// StreamDeltas is what gameInstance.broadcastUpdates needs of the boards after a turn (server.go:612-777), for the stream
+// of `playerID`, for every game at once: kind[env] = 1 -> send a GameStateDelta whose tile updates are
+// updates[offset[env]:offset[env+1]] (bits 0-15 tile index, 16-17 core tile type after the fog rules, 18 visible,
+// 19 fog_of_war, 20-23 owner+1, 32-63 army); kind[env] = 2 -> createStreamUpdate falls back to the full state
+// (convertGameStateToProto over GameState(env, 1)).  PlayerUpdates come from GameState's per-player fields.
+func (e *VecEngine) StreamDeltas(playerID int) (kind []uint8, offset []int64, updates []uint64, err error) {
+	B := e.cfg.NumEnvs
+	capacity := B * int(C.gvec_stream_delta_cap(e.h))
+	kind, offset, updates = make([]uint8, B), make([]int64, B+1), make([]uint64, capacity)
+	var total C.int64_t
+	rc := C.gvec_stream_deltas_packed(e.h, C.int32_t(playerID), (*C.uint8_t)(unsafe.Pointer(&kind[0])), (*C.int64_t)(unsafe.Pointer(&offset[0])),
+		(*C.uint64_t)(unsafe.Pointer(&updates[0])), C.int64_t(capacity), &total)
+	return kind, offset, updates[:int(total)], apiErr(rc, "gvec_stream_deltas_packed")
+}
+
