@@ -79,7 +79,7 @@ SYMBOLS = {
     "gvec_gym_step": (_i32, [_vp, _i32, _u64] + [_vp] * 3 + [_i32] + [_vp] * 11),
     "gvec_stream_delta_cap": (_i32, [_vp]),
     "gvec_stream_deltas": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32]),
-    "gvec_stream_deltas_packed": (_i32, [_vp, _i32, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "gvec_stream_deltas_packed": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "gvec_observe": (_i32, [_vp, _i32, _vp, _i32]),
     "gvec_serializer_mask": (_i32, [_vp, _vp, _i32]),
     "gvec_export_records": (_i32, [_vp, _i32, _i32, _vp]),

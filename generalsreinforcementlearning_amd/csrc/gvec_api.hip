@@ -1489,12 +1489,12 @@ int32_t gvec_stream_deltas(gvec_handle* h, int32_t player, uint8_t* kind, int32_
   return GVEC_OK;
 }
 
-int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, uint8_t* kind, int64_t* offset, uint64_t* updates, int64_t capacity,
-                                  int64_t* total) {
+int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, int32_t full_tiles, uint8_t* kind, int64_t* offset, uint64_t* updates,
+                                  int64_t capacity, int64_t* total) {
   if (!h || !kind || !offset || !updates || !total || capacity < 0 || player < 0 || player >= h->maxp) return GVEC_E_INVALID;
   if (h->sharded()) return sharded::unsupported("gvec_stream_deltas_packed");
   HIPCHK(hipSetDevice(h->cfg.device));
-  const int cap = gvec_stream_delta_cap(h);
+  const int cap = full_tiles ? h->stride : gvec_stream_delta_cap(h);   // rows long enough for a whole board when asked for
   const size_t B = (size_t)h->cfg.num_envs;
   DevBuf bk(h, 0), bc(h, 1), bu(h, 2), bo(h, 3), bp(h, 4);
   HIPCHK(bk.alloc(B));
@@ -1513,6 +1513,7 @@ int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, uint8_t* kind,
   a.row_dw = h->row_dw;
   a.player = player;
   a.cap = cap;
+  a.full_tiles = full_tiles ? 1 : 0;
   a.kind = bk.as<uint8_t>();
   a.count = bc.as<int32_t>();
   a.updates = bu.as<unsigned long long>();

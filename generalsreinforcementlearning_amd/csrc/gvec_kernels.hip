@@ -1130,11 +1130,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stream_delta_kernel(Stre
   const int total = nc + nv;
   const bool delta = total > 0 && total < b.N / 5;       // :640 (integer division)
   const int n_union = b.count(b.chg | b.vch);            // a wave-wide reduction: every lane takes part
+  const bool all_tiles = !delta && A.full_tiles != 0;     // the full state's tiles (server.go:556-582) for envs that get no delta
   if (lane == 0) {
     A.kind[env] = (uint8_t)(delta ? 1 : 2);
-    A.count[env] = delta ? n_union : 0;
+    A.count[env] = delta ? n_union : (all_tiles ? b.N : 0);
   }
-  if (!delta) return;                                     // wave-uniform
+  if (!delta && !all_tiles) return;                       // wave-uniform
   const bool fog_on = (b.hflags & HF_FOG) != 0u;
   uint32_t vis_p = 0u;
 #pragma unroll
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stream_delta_kernel(Stre
   int base = 0;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const uint32_t sel_plane = pass == 0 ? b.chg : (b.vch & ~b.chg);
+    const uint32_t sel_plane = all_tiles ? (pass == 0 ? b.valid : 0u) : (pass == 0 ? b.chg : (b.vch & ~b.chg));
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
       const int t = 64 * s + lane;

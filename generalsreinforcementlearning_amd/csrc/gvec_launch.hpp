@@ -197,6 +197,7 @@ struct StreamDeltaArgs {
   int32_t* count;                // [B] tile updates of the delta
   unsigned long long* updates;   // [B][cap]
   int32_t num_envs, fd, row_dw, player, cap;
+  int32_t full_tiles;            // != 0: an env of kind 2 gets ALL its tiles (count = W*H, cap >= tile stride), the full state's board
 };
 hipError_t launch_stream_deltas(const Variant& v, const StreamDeltaArgs& a, hipStream_t s);
 // offset[n + 1] = exclusive prefix sum of count[n]; packed[offset[e] + k] = rows[e][k] for k < count[e] (entries beyond `capacity` dropped)

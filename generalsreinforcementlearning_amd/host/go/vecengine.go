@@ -311,7 +311,7 @@ func (e *VecEngine) StreamDeltas(playerID int) (kind []uint8, offset []int64, up
 	capacity := B * int(C.gvec_stream_delta_cap(e.h))
 	kind, offset, updates = make([]uint8, B), make([]int64, B+1), make([]uint64, capacity)
 	var total C.int64_t
-	rc := C.gvec_stream_deltas_packed(e.h, C.int32_t(playerID), (*C.uint8_t)(unsafe.Pointer(&kind[0])), (*C.int64_t)(unsafe.Pointer(&offset[0])),
+	rc := C.gvec_stream_deltas_packed(e.h, C.int32_t(playerID), 0, (*C.uint8_t)(unsafe.Pointer(&kind[0])), (*C.int64_t)(unsafe.Pointer(&offset[0])),
 		(*C.uint64_t)(unsafe.Pointer(&updates[0])), C.int64_t(capacity), &total)
 	return kind, offset, updates[:int(total)], apiErr(rc, "gvec_stream_deltas_packed")
 }

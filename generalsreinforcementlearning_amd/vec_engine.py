@@ -273,15 +273,18 @@ class VecEngine:
         check(self.L.gvec_stream_deltas(self.h, player, _ptr(kind), _ptr(count), _ptr(upd), MEM_HOST), "gvec_stream_deltas")
         return kind, count, upd
 
-    def stream_deltas_packed(self, player):
+    def stream_deltas_packed(self, player, full_tiles=False):
         """-> kind[B], offset[B + 1], updates[total]: env e's updates are updates[offset[e]:offset[e + 1]] - only the updates
-        that exist cross PCIe (gvec_stream_deltas_packed).  The landing buffers are page-locked and reused by the next call."""
-        cap = self.L.gvec_stream_delta_cap(self.h)
-        if not hasattr(self, "_sd"):
-            self._sd = (self.pinned((self.B,), np.uint8), self.pinned((self.B + 1,), np.int64), self.pinned((self.B * cap,), np.uint64))
-        kind, off, upd = self._sd
+        that exist cross PCIe (gvec_stream_deltas_packed).  full_tiles: an env the server would send a full state for
+        (kind 2) contributes all its tiles, fog rules applied, so no board is ever read back.  The landing buffers are
+        page-locked and reused by the next call."""
+        cap = self.stride if full_tiles else self.L.gvec_stream_delta_cap(self.h)
+        key = "_sd_full" if full_tiles else "_sd"
+        if not hasattr(self, key):
+            setattr(self, key, (self.pinned((self.B,), np.uint8), self.pinned((self.B + 1,), np.int64), self.pinned((self.B * cap,), np.uint64)))
+        kind, off, upd = getattr(self, key)
         total = C.c_int64()
-        check(self.L.gvec_stream_deltas_packed(self.h, player, _ptr(kind), _ptr(off), _ptr(upd), self.B * cap, C.byref(total)),
+        check(self.L.gvec_stream_deltas_packed(self.h, player, int(bool(full_tiles)), _ptr(kind), _ptr(off), _ptr(upd), self.B * cap, C.byref(total)),
               "gvec_stream_deltas_packed")
         return kind, off, upd[: total.value]
 

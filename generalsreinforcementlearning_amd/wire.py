@@ -240,6 +240,25 @@ def stream_update_from_delta(st, kind, count, updates, e, viewer, names=None):
     return up
 
 
+def full_state_from_tiles(st, tiles, legal_mask, e, viewer, game_id="", names=None):
+    """convertGameStateToProto for env e from the packed tiles gvec_stream_deltas_packed(full_tiles=1) delivers for an env
+    of kind 2 (all W*H tiles, ascending, fog rules applied): `game_state` without a board read-back."""
+    w, h, P = int(st["width"][e]), int(st["height"][e]), int(st["players"][e])
+    names = names or [f"player{p}" for p in range(P)]
+    done = bool(st["done"][e])
+    gs = GameState(game_id=game_id, status=STATUS_FINISHED if done else STATUS_IN_PROGRESS, turn=int(st["turn"][e]),
+                   winner_id=int(st["winner"][e]) if done else -1, current_phase=PHASE_ENDED if done else PHASE_RUNNING)
+    gs.board.width, gs.board.height = w, h
+    for u in tiles:
+        u = int(u)
+        army = (u >> 32) & 0xFFFFFFFF
+        gs.board.tiles.add(type=TILE_TYPE[(u >> 16) & 3], owner_id=((u >> 20) & 0xF) - 1, army_count=army - (1 << 32) if army >= 1 << 31 else army,
+                           visible=bool((u >> 18) & 1), fog_of_war=bool((u >> 19) & 1))
+    gs.players.extend(_player_state(st, e, p, names[p], viewer, delta=False) for p in range(P))
+    gs.action_mask.extend(bool(v) for v in legal_mask)
+    return gs
+
+
 def experience(d, collector_version="1.0.0"):
     """One experience dict (VecExperienceCollector.as_dicts / decode_records) -> experiencepb.Experience as
     SimpleCollector.OnStateTransition fills it (collector.go:58-83)."""

@@ -390,10 +390,12 @@ int32_t gvec_stream_deltas(gvec_handle* h, int32_t player, uint8_t* kind, int32_
 /* The same updates as ONE stream (host memory): env e's updates are updates[offset[e] .. offset[e + 1]), offset has B + 1
  * entries, *total = offset[B].  Only the updates that exist cross PCIe - about 11 per env-turn at 20x20 4P, 25 MB for
  * 262,144 boards instead of the 168 MB of the fixed-stride form or the 1 GB of the boards.  capacity = the entries
- * `updates` can hold: GVEC_E_RANGE (with *total set) when it is too small; B * gvec_stream_delta_cap(h) always suffices.
- * Plain handles only. */
-int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, uint8_t* kind, int64_t* offset, uint64_t* updates, int64_t capacity,
-                                  int64_t* total);
+ * `updates` can hold: GVEC_E_RANGE (with *total set) when it is too small; B * gvec_stream_delta_cap(h) always suffices
+ * (B * tile_stride with full_tiles).  full_tiles != 0: an env of kind 2 contributes ALL its W*H tiles in the same packed
+ * form, ascending - the board of convertGameStateToProto's full state with the player's fog rules applied
+ * (server.go:556-582) - so that a broadcast never reads a board back, growth turns included.  Plain handles only. */
+int32_t gvec_stream_deltas_packed(gvec_handle* h, int32_t player, int32_t full_tiles, uint8_t* kind, int64_t* offset, uint64_t* updates,
+                                  int64_t capacity, int64_t* total);
 
 /* ---- python/generals_gym on the device ------------------------------------------
  * What GeneralsEnv builds on the client from the GameState proto of its player token, computed straight

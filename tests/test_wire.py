@@ -274,6 +274,8 @@ def test_device_stream_deltas_equal_create_stream_update(fog):
             pk, poff, pupd = eng.stream_deltas_packed(viewer)         # the same updates as one stream
             assert np.array_equal(pk, kind) and np.array_equal(np.diff(poff), count) and poff[0] == 0
             assert np.array_equal(pupd, np.concatenate([upd[e_, : count[e_]] for e_ in range(B)]))
+            fk, foff, fupd = eng.stream_deltas_packed(viewer, full_tiles=True)   # kind-2 envs carry their whole board
+            assert np.array_equal(fk, kind)
             k2, c2, u2 = many.stream_deltas(viewer)
             assert np.array_equal(kind, k2) and np.array_equal(count, c2)
             vis, fg = eng.compute_player_visibility(viewer)
@@ -285,9 +287,14 @@ def test_device_stream_deltas_equal_create_stream_update(fog):
                 want = wire.stream_update(st, vis, fg, np.zeros(w * h * 4, bool), e, viewer)
                 got = wire.stream_update_from_delta(st, kind, count, upd, e, viewer)
                 seen[int(kind[e])] += 1
+                mine = fupd[foff[e]: foff[e + 1]]
                 if want.WhichOneof("update") == "full_state":
                     assert kind[e] == 2 and got is None and count[e] == 0, (k, e, viewer)
+                    assert len(mine) == w * h
+                    fs = wire.full_state_from_tiles(st, mine, np.zeros(w * h * 4, bool), e, viewer)
+                    assert fs == want.full_state, (k, e, viewer)
                 else:
+                    assert np.array_equal(mine, upd[e, : count[e]])
                     assert kind[e] == 1 and got is not None, (k, e, viewer)
                     want.ClearField("timestamp")
                     got.ClearField("timestamp")
