@@ -116,3 +116,19 @@ def test_bench_two_ranks_with_real_engines_on_one_gpu():
     assert d["board_launches"] == 16384 * 12 and 0.99 * d["board_launches"] <= d["env_steps_played"] <= d["board_launches"]
     g_ = d["experience_gather"]
     assert g_["ranks_seen"] == [0, 1] and g_["records_per_rank_per_gather"] == 512 and g_["experiences_decoded_last_step"] > 512
+
+
+@pytest.mark.gpu
+def test_bench_three_ranks_strong_scaling_with_real_engines_on_one_gpu():
+    """BASELINE configs[3]'s form - a fixed total sharded across the ranks - with a total that does not divide: shards of
+    5,462 / 5,461 / 5,461 boards, equal gather slabs, records tagged with global env ids of all three shards."""
+    env = dict(_plain_env(), GVEC_BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "8", "--warmup", "2",
+                        "--total-envs", "16384", "--gather-envs", "8192", "--gather-every", "2", "--pool", "256", "--prewarm-s", "0.05",
+                        "--no-cpu-baseline", "--no-fused"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d["scaling"] == "strong" and d["config"]["total_envs"] == 16384 and d["config"]["envs_per_gpu"] == 5462
+    assert d["board_launches"] == 16384 * 8 and d["env_steps_played"] <= d["board_launches"]
+    g_ = d["experience_gather"]
+    assert g_["records_per_rank_per_gather"] == 5461 and g_["ranks_seen"] == [0, 1, 2]
