@@ -80,3 +80,25 @@ def test_sharded_create_fails_loudly_without_a_gpu():
     devs = (C.c_int32 * 2)(0, 1)
     assert L.gvec_create_sharded(C.byref(cfg), devs, 2, C.byref(h)) == -2 and not h.value   # GVEC_E_NO_DEVICE
     assert b"no CPU fallback" in L.gvec_last_error()
+
+
+def test_new_entry_points_validate_their_arguments_without_a_gpu():
+    """Argument checks come before anything touches a device: they hold on a CPU-only box too."""
+    import ctypes as C
+    import generalsreinforcementlearning_amd as g
+    L = g.load()
+    bad = (C.c_int32 * 8)(10, 2, 4, 2, 2, 100, 0, 0)                      # record_dw far too small for this layout
+    p = C.c_void_p(16)
+    assert L.gvec_expand_experience_records(0, None, bad, p, 4, p, p, p, p) == -1 and b"layout" in L.gvec_last_error()
+    assert L.gvec_expand_experience_records(0, None, bad, None, 4, p, p, p, p) == -1
+    ok = (C.c_int32 * 8)(4 + 4 + (16 + 3) * 4 + 2 * 64, 2, 4, 2, 2, 100, 0, 0)
+    assert L.gvec_expand_experience_records(0, None, ok, p, 0, p, p, p, p) == 0   # nothing to expand: no device needed
+    assert L.gvec_stream_delta_cap(None) == -1 and L.gvec_num_shards(None) == -1
+    from generalsreinforcementlearning_amd._lib import Config
+    cfg = Config()
+    L.gvec_config_default(C.byref(cfg))
+    h = C.c_void_p()
+    assert L.gvec_create_sharded(C.byref(cfg), None, 2, C.byref(h)) == -1
+    assert L.gvec_create_sharded(C.byref(cfg), (C.c_int32 * 1)(0), 0, C.byref(h)) == -1
+    out = C.c_void_p()
+    assert L.gvec_host_alloc(0, C.byref(out)) == -1 and L.gvec_host_free(None) == 0
