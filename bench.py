@@ -308,6 +308,10 @@ def main():
                     help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="N>1 only: the record gather runs on every K-th step (BASELINE configs[3]: 'RCCL gather each K turns')")
+    ap.add_argument("--record-overlap", type=int, default=1,
+                    help="N>1 only: 1 = on a gathering step the sampled slice (snapshot -> its turn -> record kernels) runs on a second "
+                         "compute stream beside the turn of the rest of the batch (gvec_rollout_range); 0 = everything in line on one stream")
+    ap.add_argument("--fingerprint", action="store_true", help="diagnostics: add a sha256 of the final headers and legal masks to the line")
     ap.add_argument("--gather-mode", type=int, default=0,
                     help="diagnostics: 1 = record kernels only (no collective), 2 = collective on the compute stream (no side stream)")
     ap.add_argument("--mixed", action="store_true",
@@ -433,6 +437,7 @@ def main():
             rgs = [RecordGather(ge * eng.experience_record_bytes(), dev, dst=0) for _ in range(2)] if ge > 0 else None
         slab_free = [None, None]
         side = torch.cuda.Stream()
+        rec_stream = torch.cuda.Stream()           # the sampled slice's own compute stream (--record-overlap)
         if rgs is not None:
             # the gather's send/recv channels connect lazily too: one untimed gather per slab, on the side stream it will use
             with torch.cuda.stream(side):
@@ -443,8 +448,37 @@ def main():
 
     K = max(1, args.gather_every)
 
+    def one_step_overlapped(k):
+        """A gathering step with the sampled slice on its own stream: snapshot -> the slice's turn (its moves recorded) ->
+        record kernels run BESIDE the turn of the other boards (disjoint envs: gvec_rollout_range), so the three small,
+        latency-bound kernels (~30 us in line) hide behind the 0.2-ms launch; the next step waits for both."""
+        lo = ((k // K) * ge) % max(1, B - ge + 1)
+        i = (k // K) & 1
+        rec_stream.wait_stream(stream)                                 # the previous turn is done
+        if slab_free[i] is not None:
+            rec_stream.wait_event(slab_free[i])                        # slab i was last read by the gather before the previous one
+        eng.set_stream(rec_stream.cuda_stream)
+        eng.experience_begin_range(lo, ge)
+        eng.record_agent_actions(True)
+        eng.rollout_range(lo, ge, 1, seed, 0)
+        eng.record_agent_actions(False)
+        eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, env_base)
+        eng.set_stream(stream.cuda_stream)
+        done = rec_stream.record_event()
+        if lo > 0:
+            eng.rollout_range(0, lo, 1, seed, 0)
+        if lo + ge < B:
+            eng.rollout_range(lo + ge, B - lo - ge, 1, seed, 0)
+        stream.wait_event(done)                                        # the next turn touches the slice again
+        side.wait_event(done)
+        with torch.cuda.stream(side):
+            rgs[i].gather()                                            # RCCL gather over xGMI, overlapped with the next steps
+            slab_free[i] = side.record_event()
+
     def one_step(k):
         gathering = rgs is not None and k % K == K - 1
+        if gathering and args.record_overlap and args.gather_mode == 0:
+            return one_step_overlapped(k)
         if gathering:
             lo = ((k // K) * ge) % max(1, B - ge + 1)
             eng.experience_begin_range(lo, ge)                    # captureStateForExperience for the sampled slice
@@ -617,6 +651,14 @@ def main():
         }
         if reset_cost:
             out["reset_cost"] = reset_cost
+        if args.fingerprint:
+            import ctypes as C
+            hh = hashlib.sha256()
+            for which, nbytes in ((0, B * 24 * 4), (3, B * P * eng.mask_bytes)):
+                buf = (C.c_uint8 * nbytes)()
+                g._lib.check(eng.L.gvec_read_buffer(eng.h, which, 0, nbytes, buf), "gvec_read_buffer")
+                hh.update(bytes(buf))
+            out["state_fingerprint"] = hh.hexdigest()[:24]
         if same_dev:
             out["rehearsal_same_device"] = True   # N ranks on ONE GPU over gloo: a choreography check, not a measurement
         if gathered:

@@ -61,6 +61,7 @@ SYMBOLS = {
     "gvec_read_state": (_i32, [_vp, _i32, _i32, C.POINTER(StateView), _i32]),
     "gvec_write_state": (_i32, [_vp, _i32, _i32, C.POINTER(StateView), _i32]),
     "gvec_rollout": (_i32, [_vp, _i32, _u64, _i32, _i32, C.POINTER(RolloutStats)]),
+    "gvec_rollout_range": (_i32, [_vp, _i32, _i32, _i32, _u64, _i32]),
     "gvec_set_agent_mix": (_i32, [_vp, _i32, _i32]),
     "gvec_agent_actions": (_i32, [_vp, _u64, _i32, _vp, _i32]),
     "gvec_counters": (_i32, [_vp, C.POINTER(RolloutStats)]),

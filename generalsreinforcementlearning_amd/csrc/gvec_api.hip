@@ -1099,6 +1099,37 @@ int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed, int32_t inval
   return GVEC_OK;
 }
 
+int32_t gvec_rollout_range(gvec_handle* h, int32_t env_begin, int32_t n, int32_t turns, uint64_t seed, int32_t invalid_permille) {
+  if (!h || turns < 0) return GVEC_E_INVALID;
+  if (h->sharded()) return sharded::unsupported("gvec_rollout_range");
+  if (env_begin < 0 || n < 0 || env_begin + n > h->cfg.num_envs) return GVEC_E_RANGE;
+  if (n == 0 || turns == 0) return GVEC_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->legal_valid) RET_IF(refresh_legal(h));
+  // the same launch as gvec_rollout's per-turn path over a slice: every per-env array starts at the slice, and the slice's
+  // first env keeps its index in the batch for the agent / pool keys (env_base)
+  StepArgs a = base_args(h);
+  a.flags |= KF_AGENT | KF_EMIT | KF_LMVALID;
+  a.seed_lo = (uint32_t)seed;
+  a.seed_hi = (uint32_t)(seed >> 32);
+  a.invalid_permille = invalid_permille;
+  a.turns = 1;
+  const size_t e = (size_t)env_begin;
+  a.hdr += e * HDR_DW;
+  a.rows += e * h->row_dw;
+  a.army16 += e * (h->army_dw / 2);
+  a.army32 += e * h->army_dw;
+  a.legal += e * h->maxp * h->mask_dw;
+  a.num_envs = n;
+  a.env_base = h->env_base + env_begin;
+  if (h->record_actions) {
+    a.actions_out = h->d_actions + e * h->maxp;
+    a.err = h->d_err + e;
+  }
+  for (int k = 0; k < turns; ++k) HIPCHK(launch_step(h->var, a, h->stream));
+  return GVEC_OK;
+}
+
 int32_t gvec_set_agent_mix(gvec_handle* h, int32_t noop_per_65536, int32_t half_per_65536) {
   if (!h) return GVEC_E_INVALID;
   if (h->sharded()) {

@@ -318,6 +318,10 @@ class VecEngine:
               "gvec_rollout")
         return {"env_steps": st.env_steps, "aborted_turns": st.aborted_turns, "games_finished": st.games_finished} if want_stats else None
 
+    def rollout_range(self, env_begin, n, turns, seed, invalid_permille=0):
+        """Per-turn rollout of envs [env_begin, env_begin + n) only (gvec_rollout_range); enqueued, not synchronised."""
+        check(self.L.gvec_rollout_range(self.h, env_begin, n, turns, seed, invalid_permille), "gvec_rollout_range")
+
     # ---- internal/experience side channel (serializer.go, rewards.go) --------------------------------
     def experience_begin(self):
         """TurnProcessor.captureStateForExperience (turn_processor.go:116-121): snapshot before the step."""

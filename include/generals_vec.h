@@ -278,6 +278,11 @@ int32_t gvec_write_state(gvec_handle* h, int32_t env_begin, int32_t n,
 int32_t gvec_rollout(gvec_handle* h, int32_t turns, uint64_t seed,
                      int32_t invalid_permille, int32_t fused,
                      gvec_rollout_stats* stats);
+/* The per-turn rollout (fused = 0, no statistics) for envs [env_begin, env_begin + n) only: the same launch over a slice
+ * of the batch.  Disjoint slices may be stepped on different streams (gvec_set_stream before each call) and overlap on the
+ * GPU - how a consumer steps a sampled slice together with its snapshot / record kernels beside the rest of the batch
+ * (bench.py's gathering steps).  Stepping every env exactly once, slice by slice, equals one gvec_rollout turn. */
+int32_t gvec_rollout_range(gvec_handle* h, int32_t env_begin, int32_t n, int32_t turns, uint64_t seed, int32_t invalid_permille);
 /* The agent's mix: a player sits a turn out when (draw & 0xFFFF) < noop_per_65536 (default 6554,
  * p = 0.1) and moves half its army when (draw >> 16) < half_per_65536 (default 19661, p = 0.3).
  * (45875, 19661) are the rates of the reference's game.GenerateRandomActions (demo_helpers.go:20,44:

@@ -132,3 +132,25 @@ def test_bench_three_ranks_strong_scaling_with_real_engines_on_one_gpu():
     assert d["board_launches"] == 16384 * 8 and d["env_steps_played"] <= d["board_launches"]
     g_ = d["experience_gather"]
     assert g_["records_per_rank_per_gather"] == 5461 and g_["ranks_seen"] == [0, 1, 2]
+
+
+@pytest.mark.gpu
+def test_bench_overlapped_record_chain_changes_nothing_but_the_time():
+    """--record-overlap 1 (the sampled slice's snapshot -> turn -> records on a second compute stream beside the rest of the
+    batch) against --record-overlap 0 (everything in line): the same games - final headers and masks, played / aborted /
+    finished counts - and the same gathered experiences.  World size 1 over real RCCL (--force-dist)."""
+    outs = []
+    for overlap in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "30", "--warmup", "6",
+                            "--envs-per-gpu", "20000", "--gather-envs", "1500", "--gather-every", "3", "--pool", "64", "--prewarm-s", "0.05",
+                            "--width", "12", "--height", "12", "--players", "3", "--record-overlap", overlap, "--fingerprint",
+                            "--no-cpu-baseline", "--no-fused"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=_plain_env())
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        outs.append(json.loads(lines[0]))
+    a, b = outs
+    for k in ("state_fingerprint", "env_steps_played", "aborted_turns", "games_finished", "board_launches"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a["experience_gather"]["experiences_decoded_last_step"] == b["experience_gather"]["experiences_decoded_last_step"] > 1500
+    assert a["games_finished"] >= 0 and a["env_steps_played"] > 0.99 * a["board_launches"]

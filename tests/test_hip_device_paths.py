@@ -234,3 +234,37 @@ def test_pinned_host_buffers_give_the_same_results(g):
     assert all(np.array_equal(sa[f], sb[f]) for f in sa)
     b.close()
     a.close()
+
+
+def test_rollout_range_slices_equal_one_full_turn(g):
+    """gvec_rollout_range: stepping every env exactly once, slice by slice (also on different streams, overlapping), is one
+    gvec_rollout turn - agent keys, pool re-deals, masks, recorded moves and error codes included."""
+    import torch
+    B = 3000
+    a = g.VecEngine(B, 12, 12, 3, auto_reset=True, stream=torch.cuda.current_stream().cuda_stream)
+    b = g.VecEngine(B, 12, 12, 3, auto_reset=True, stream=torch.cuda.current_stream().cuda_stream)
+    for e in (a, b):
+        e.reset_generated(8)
+        e.build_board_pool(16, 3)
+        e.record_agent_actions(True)
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    cuts = [0, 1, 640, 641, 1999, B]
+    for k in range(160):
+        a.rollout(1, 5, 9, fused=False, want_stats=False)
+        # b: the slices alternate between two streams; both wait for the previous turn, the next turn waits for both
+        side.wait_stream(main)
+        for i in range(len(cuts) - 1):
+            b.set_stream((side if i % 2 else main).cuda_stream)
+            b.rollout_range(cuts[i], cuts[i + 1] - cuts[i], 1, 5, 9)
+        b.set_stream(main.cuda_stream)
+        main.wait_stream(side)
+        if k % 20 == 19:
+            sa, sb = a.game_state(), b.game_state()
+            assert all(np.array_equal(sa[f], sb[f]) for f in sa), k
+            assert np.array_equal(a.legal_action_mask_bits(), b.legal_action_mask_bits())
+            assert np.array_equal(a.recorded_actions(), b.recorded_actions()) and np.array_equal(a.last_errors(), b.last_errors())
+    assert a.counters() == b.counters() and a.counters()["games_finished"] > 0
+    with pytest.raises(g.GvecError):
+        b.rollout_range(2990, 20, 1, 5)
+    a.close(); b.close()
