@@ -142,7 +142,7 @@ def test_bench_overlapped_record_chain_changes_nothing_but_the_time():
     outs = []
     for overlap in ("1", "0"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "30", "--warmup", "6",
-                            "--envs-per-gpu", "20000", "--gather-envs", "1500", "--gather-every", "3", "--pool", "64", "--prewarm-s", "0.05",
+                            "--envs-per-gpu", "20000", "--gather-envs", "1500", "--gather-every", "3", "--pool", "64", "--prewarm-s", "0",
                             "--width", "12", "--height", "12", "--players", "3", "--record-overlap", overlap, "--fingerprint",
                             "--no-cpu-baseline", "--no-fused"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=_plain_env())
         assert r.returncode == 0, r.stderr[-3000:]
