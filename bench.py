@@ -308,9 +308,11 @@ def main():
                     help="N>1 only: compact records per rank gathered to rank 0 each step (experience slab; 0 = off)")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="N>1 only: the record gather runs on every K-th step (BASELINE configs[3]: 'RCCL gather each K turns')")
-    ap.add_argument("--record-overlap", type=int, default=1,
+    ap.add_argument("--record-overlap", type=int, default=0,
                     help="N>1 only: 1 = on a gathering step the sampled slice (snapshot -> its turn -> record kernels) runs on a second "
-                         "compute stream beside the turn of the rest of the batch (gvec_rollout_range); 0 = everything in line on one stream")
+                         "compute stream beside the turn of the rest of the batch (gvec_rollout_range); 2 = also the boards after the slice "
+                         "on a stream of their own; 0 (default) = everything in line on one stream.  Measured neutral: the three are within "
+                         "run-to-run noise of each other (DESIGN.md section 8)")
     ap.add_argument("--fingerprint", action="store_true", help="diagnostics: add a sha256 of the final headers and legal masks to the line")
     ap.add_argument("--gather-mode", type=int, default=0,
                     help="diagnostics: 1 = record kernels only (no collective), 2 = collective on the compute stream (no side stream)")
@@ -438,6 +440,7 @@ def main():
         slab_free = [None, None]
         side = torch.cuda.Stream()
         rec_stream = torch.cuda.Stream()           # the sampled slice's own compute stream (--record-overlap)
+        rest_stream = torch.cuda.Stream()          # --record-overlap 2: the boards after the slice
         if rgs is not None:
             # the gather's send/recv channels connect lazily too: one untimed gather per slab, on the side stream it will use
             with torch.cuda.stream(side):
@@ -465,10 +468,22 @@ def main():
         eng.experience_records(rgs[i].send.data_ptr(), None, lo, ge, env_base)
         eng.set_stream(stream.cuda_stream)
         done = rec_stream.record_event()
+        # the boards before and after the slice: two launches that would drain and refill the GPU one after the other on
+        # one stream - the second one goes to its own stream and fills the machine together with the first
+        tail_done = None
+        if lo + ge < B:
+            if lo > 0 and args.record_overlap >= 2:
+                rest_stream.wait_stream(stream)
+                eng.set_stream(rest_stream.cuda_stream)
+                eng.rollout_range(lo + ge, B - lo - ge, 1, seed, 0)
+                eng.set_stream(stream.cuda_stream)
+                tail_done = rest_stream.record_event()
+            else:
+                eng.rollout_range(lo + ge, B - lo - ge, 1, seed, 0)
         if lo > 0:
             eng.rollout_range(0, lo, 1, seed, 0)
-        if lo + ge < B:
-            eng.rollout_range(lo + ge, B - lo - ge, 1, seed, 0)
+        if tail_done is not None:
+            stream.wait_event(tail_done)
         stream.wait_event(done)                                        # the next turn touches the slice again
         side.wait_event(done)
         with torch.cuda.stream(side):
