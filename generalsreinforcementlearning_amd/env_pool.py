@@ -43,10 +43,10 @@ class ReplayBuffer:
             raise ValueError(f"capacity must be positive, got {capacity}")   # replay_buffer.py:22-23
         self.capacity = int(capacity)
         self._state = self._next = self._action = self._reward = self._done = None
-        self._size = 0
-        self._write_idx = 0
-        self._total_pushed = 0
-        self._lock = threading.Lock()
+        self._size = 0          # transitions held
+        self._cursor = 0        # slot the next transition goes to
+        self._pushed = 0        # every push since construction
+        self._guard = threading.Lock()
 
     def _alloc(self, state):
         s = np.asarray(state)
@@ -57,33 +57,33 @@ class ReplayBuffer:
         self._done = np.empty(self.capacity, bool)
 
     def push(self, state, action, reward, next_state, done):
-        with self._lock:
+        with self._guard:
             if self._state is None:
                 self._alloc(state)
-            i = self._write_idx
-            self._state[i], self._next[i] = state, next_state
-            self._action[i], self._reward[i], self._done[i] = action, reward, done
-            self._write_idx = (i + 1) % self.capacity                       # :36
+            slot = self._cursor
+            self._state[slot], self._next[slot] = state, next_state
+            self._action[slot], self._reward[slot], self._done[slot] = action, reward, done
+            self._cursor = (slot + 1) % self.capacity                       # the oldest slot is the next to go (:31-36)
             self._size = min(self._size + 1, self.capacity)
-            self._total_pushed += 1
+            self._pushed += 1
 
     def push_batch(self, states, actions, rewards, next_states, dones):
         """k transitions in order (equivalent to k `push` calls) under one lock."""
         k = len(actions)
         if k == 0:
             return
-        with self._lock:
+        with self._guard:
             if self._state is None:
                 self._alloc(states[0])
-            idx = (self._write_idx + np.arange(k)) % self.capacity
+            idx = (self._cursor + np.arange(k)) % self.capacity
             if k > self.capacity:                                            # only the last `capacity` survive, as with k pushes
                 keep = slice(k - self.capacity, k)
                 idx, states, actions, rewards, next_states, dones = idx[keep], states[keep], actions[keep], rewards[keep], next_states[keep], dones[keep]
             self._state[idx], self._next[idx] = states, next_states
             self._action[idx], self._reward[idx], self._done[idx] = actions, rewards, dones
-            self._write_idx = (self._write_idx + k) % self.capacity
+            self._cursor = (self._cursor + k) % self.capacity
             self._size = min(self._size + k, self.capacity)
-            self._total_pushed += k
+            self._pushed += k
 
     def _item(self, i):
         return (self._state[i], int(self._action[i]), float(self._reward[i]), self._next[i], bool(self._done[i]))
@@ -91,22 +91,22 @@ class ReplayBuffer:
     def sample(self, batch_size):
         """List of (state, action, reward, next_state, done) tuples, like the reference (:40-43); ValueError when the
         buffer holds fewer than batch_size transitions (random.sample's own)."""
-        with self._lock:
+        with self._guard:
             return [self._item(i) for i in random.sample(range(self._size), batch_size)]
 
     def sample_arrays(self, batch_size):
         """The same draw as stacked arrays: (states, actions, rewards, next_states, dones)."""
-        with self._lock:
+        with self._guard:
             idx = np.asarray(random.sample(range(self._size), batch_size), np.int64)
             return self._state[idx], self._action[idx], self._reward[idx], self._next[idx], self._done[idx]
 
     @property
     def total_pushed(self):
-        with self._lock:
-            return self._total_pushed
+        with self._guard:
+            return self._pushed
 
     def __len__(self):
-        with self._lock:
+        with self._guard:
             return self._size
 
 
@@ -115,22 +115,17 @@ class ParallelVecEnvPool:
 
     def __init__(self, num_envs, env_factory, action_fn, replay_buffer, max_steps_per_episode=200, max_env_retries=3, seed=42,
                  batched_actions=False, retry_sleep_s=2.0):
-        self.num_envs = num_envs
-        self.env_factory = env_factory
-        self.action_fn = action_fn
-        self.replay_buffer = replay_buffer
-        self.max_steps_per_episode = max_steps_per_episode
-        self.max_env_retries = max_env_retries
-        self.seed = seed
-        self.batched_actions = bool(batched_actions)
-        self.retry_sleep_s = retry_sleep_s
-
-        self._stop_event = threading.Event()
-        self._threads = []
-        self._stats_lock = threading.Lock()
-        self._total_episodes = 0
-        self._alive_workers = 0
-        self._episode_results = []     # (episode_reward, episode_length, worker_id), drained by the trainer
+        # the reference's public attributes (vector_env.py:45-51)
+        (self.num_envs, self.env_factory, self.action_fn, self.replay_buffer, self.max_steps_per_episode, self.max_env_retries,
+         self.seed) = num_envs, env_factory, action_fn, replay_buffer, max_steps_per_episode, max_env_retries, seed
+        self.batched_actions, self.retry_sleep_s = bool(batched_actions), retry_sleep_s
+        # one collector instead of one thread per env
+        self._halt = threading.Event()
+        self._collector = None
+        self._tally = threading.Lock()          # guards the three fields below
+        self._episodes_done = 0
+        self._live = 0
+        self._finished = []                     # (episode_reward, episode_length, worker_id) since the last pop
         # private RNG per worker (vector_env.py:136-138): shared module-level RNGs would correlate exploration between workers
         self._rngs = [random.Random(self.seed * 1000 + w) for w in range(num_envs)]
         self._env = None
@@ -141,64 +136,68 @@ class ParallelVecEnvPool:
 
     # ---- the reference's public surface (vector_env.py:62-112) ----------------------------------------------
     def start(self):
-        """One daemon collector thread for all environments."""
-        if self._threads:
+        """Starts the collector (a daemon thread) for all environments."""
+        if self._collector is not None:
             raise RuntimeError("Pool already started")
-        self._stop_event.clear()
-        with self._stats_lock:
-            self._alive_workers = self.num_envs
-        t = threading.Thread(target=self._worker_loop, name="env-worker-vec", daemon=True)
-        self._threads.append(t)
-        t.start()
-        logger.info("Started the collector for %d envs", self.num_envs)
+        self._halt.clear()
+        with self._tally:
+            self._live = self.num_envs
+        self._collector = threading.Thread(target=self._worker_loop, name="env-worker-vec", daemon=True)
+        self._collector.start()
+        logger.info("collector started for %d envs", self.num_envs)
 
     def stop(self, join_timeout=10.0):
-        self._stop_event.set()
-        for t in self._threads:
+        """Asks the collector to finish its current vector step and waits for it; a straggler is logged, not raised
+        (the thread is a daemon)."""
+        self._halt.set()
+        t, self._collector = self._collector, None
+        if t is not None:
             t.join(timeout=join_timeout)
             if t.is_alive():
-                logger.warning("Worker %s did not stop within %.1fs", t.name, join_timeout)
-        self._threads = []
+                logger.warning("collector %s still running after %.1fs", t.name, join_timeout)
 
     @property
     def total_env_steps(self):
-        return self.replay_buffer.total_pushed
+        return self.replay_buffer.total_pushed      # one transition pushed == one environment step
 
     @property
     def total_episodes(self):
-        with self._stats_lock:
-            return self._total_episodes
+        with self._tally:
+            return self._episodes_done
 
     @property
     def alive_workers(self):
-        with self._stats_lock:
-            return self._alive_workers
+        with self._tally:
+            return self._live
 
     def pop_episode_results(self):
-        with self._stats_lock:
-            results = self._episode_results
-            self._episode_results = []
-            return results
+        """Finished-episode results since the last call, oldest first."""
+        with self._tally:
+            out, self._finished = self._finished, []
+        return out
 
     # ---- collection ---------------------------------------------------------------------------------------------
     def _create_env(self, old_env=None):
-        """(Re)create the vector env with retries (vector_env.py:114-134)."""
-        for attempt in range(self.max_env_retries):
+        """Opens the vector env, closing a broken predecessor first; up to max_env_retries tries, retry_sleep_s apart
+        (the reference's pattern, vector_env.py:114-134)."""
+        if old_env is not None:
             try:
-                if old_env is not None:
-                    try:
-                        old_env.close()
-                    except Exception:
-                        pass
-                    old_env = None
+                old_env.close()
+            except Exception:  # noqa: BLE001 - it is being replaced anyway
+                pass
+        tries = 0
+        while True:
+            tries += 1
+            try:
                 env = self.env_factory(self.num_envs)
-                logger.info("vector environment (re)created")
+            except Exception as e:  # noqa: BLE001
+                logger.warning("opening the vector environment failed (%d of %d): %s", tries, self.max_env_retries, e)
+                if tries >= self.max_env_retries:
+                    raise RuntimeError("failed to create the vector environment") from e
+                time.sleep(self.retry_sleep_s)
+            else:
+                logger.info("vector environment open")
                 return env
-            except Exception as e:
-                logger.warning("env creation attempt %d/%d failed: %s", attempt + 1, self.max_env_retries, e)
-                if attempt < self.max_env_retries - 1:
-                    time.sleep(self.retry_sleep_s)
-        raise RuntimeError("failed to create the vector environment")
 
     def _begin(self):
         """Every worker's first `env.reset()` (vector_env.py:166-167)."""
@@ -244,10 +243,10 @@ class ParallelVecEnvPool:
         self._ep_length[live] += 1
         over = live & (done | (self._ep_length >= self.max_steps_per_episode))
         if over.any():
-            with self._stats_lock:
-                for w in np.flatnonzero(over):
-                    self._total_episodes += 1
-                    self._episode_results.append((float(self._ep_reward[w]), int(self._ep_length[w]), int(w)))
+            ended = [(float(self._ep_reward[w]), int(self._ep_length[w]), int(w)) for w in np.flatnonzero(over)]
+            with self._tally:
+                self._episodes_done += len(ended)
+                self._finished += ended
             cut = over & ~done
             if cut.any():
                 self._env.force_reset(cut)      # the reference's next `env.reset()`: the env's own flags do not say so
@@ -267,28 +266,30 @@ class ParallelVecEnvPool:
             self._collect_step()
 
     def _worker_loop(self):
+        """The collector thread: vector steps until stop(); a step that raises costs the running episodes (like a failed
+        worker episode in the reference) and the env is reopened; when reopening fails for good the collector ends and
+        alive_workers drops to 0."""
         try:
             if self._env is None:
                 self._env = self._create_env()
                 self._begin()
-            while not self._stop_event.is_set():
+            while not self._halt.is_set():
                 try:
                     self._collect_step()
-                except Exception as e:
-                    if self._stop_event.is_set():
+                except Exception as e:  # noqa: BLE001
+                    if self._halt.is_set():
                         break
-                    logger.warning("vector step failed: %s", e)      # running episodes are lost, like a failed worker episode
+                    logger.warning("vector step failed: %s", e)
                     self._env = self._create_env(old_env=self._env)
                     self._begin()
-        except Exception as e:
-            logger.error("collector dying: %s", e)
+        except Exception as e:  # noqa: BLE001
+            logger.error("collector ends: %s", e)
         finally:
-            if self._env is not None:
+            env, self._env = self._env, None
+            if env is not None:
                 try:
-                    self._env.close()
-                except Exception:
+                    env.close()
+                except Exception:  # noqa: BLE001
                     pass
-                self._env = None
-            with self._stats_lock:
-                self._alive_workers = 0
-            logger.info("collector exited")
+            with self._tally:
+                self._live = 0

@@ -17,11 +17,11 @@ ExperienceStreamClient / ExperienceDataset with hand-built ExperienceBatch messa
 contents, drop counts, statistics, get_batch results and the dataset's draws; tests/test_experience_stream.py replays the
 same batches through this class.
 """
+import collections
 import logging
 import threading
 import time
 from dataclasses import dataclass
-from queue import Empty, Queue
 from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional
 
 import numpy as np
@@ -42,120 +42,163 @@ class ExperienceConfig:
     buffer_size: int = 1000
 
 
+class _BoundedFifo:
+    """The client's buffer: a FIFO of at most `limit` items; `offer` refuses when it is full (the caller counts the drop),
+    `take` waits up to a timeout for the next item."""
+
+    def __init__(self, limit):
+        self._items, self._limit = collections.deque(), int(limit)
+        self._ready = threading.Condition()
+
+    def offer(self, item):
+        with self._ready:
+            if self._limit > 0 and len(self._items) >= self._limit:
+                return False
+            self._items.append(item)
+            self._ready.notify()
+            return True
+
+    def take(self, timeout):
+        end = time.monotonic() + max(0.0, timeout)
+        with self._ready:
+            while not self._items:
+                left = end - time.monotonic()
+                if left <= 0 or not self._ready.wait(left):
+                    if not self._items:
+                        return None
+            return self._items.popleft()
+
+    def qsize(self):
+        with self._ready:
+            return len(self._items)
+
+
 class VecExperienceStreamClient:
-    """experience_stream_client.py:44-185 over a batch source.  `source_factory(config)` -> an iterator of batches, a batch
-    being an iterable of experience dicts (keys of `_process_experience`); it is opened by connect() - the reference's
-    channel + stub - and closed by disconnect() if it has a close()."""
+    """The surface of experience_stream_client.py:44-185 - `connect`, `disconnect`, `start_streaming`, `stop_streaming`,
+    `get_experience(timeout)`, `get_batch(batch_size, timeout)`, `get_stats()`, a `config`, a `stats` dict with the
+    reference's keys - over a batch source.  `source_factory(config)` returns an iterable of batches (a batch: an iterable
+    of experience dicts with `_process_experience`'s keys); connect() opens it where the reference opens its channel and
+    stub, disconnect() closes it if it can be closed."""
+
+    _COUNTERS = ("total_experiences", "total_batches", "dropped_experiences")
 
     def __init__(self, config: ExperienceConfig, source_factory: Callable[[ExperienceConfig], Iterable]):
-        self.config = config
-        self.source_factory = source_factory
+        self.config, self.source_factory = config, source_factory
         self.source: Optional[Iterator] = None
-        self.experience_queue = Queue(maxsize=config.buffer_size)
-        self.streaming_thread = None
+        self.experience_queue = _BoundedFifo(config.buffer_size)
         self.stop_event = threading.Event()
-        self.stats = {"total_experiences": 0, "total_batches": 0, "dropped_experiences": 0, "last_batch_time": None}
+        self.streaming_thread: Optional[threading.Thread] = None
+        self.stats: Dict[str, Any] = dict.fromkeys(self._COUNTERS, 0)
+        self.stats["last_batch_time"] = None
 
+    # ---- connection and the pump thread -----------------------------------------------------------------------
     def connect(self):
         self.source = iter(self.source_factory(self.config))
-        logger.info("Connected to the experience source (%s)", self.config.server_address)
+        logger.info("experience source open (%s)", self.config.server_address)
 
     def disconnect(self):
-        src, self.source = self.source, None
-        if src is not None and hasattr(src, "close"):
-            src.close()
-            logger.info("Disconnected from the experience source")
+        source, self.source = self.source, None
+        close = getattr(source, "close", None)
+        if close is not None:
+            close()
+            logger.info("experience source closed")
+
+    def _streaming(self):
+        t = self.streaming_thread
+        return t is not None and t.is_alive()
 
     def start_streaming(self):
-        if self.streaming_thread and self.streaming_thread.is_alive():
-            logger.warning("Streaming already started")
+        if self._streaming():
+            logger.warning("already streaming")
             return
         self.stop_event.clear()
-        self.streaming_thread = threading.Thread(target=self._stream_worker)
-        self.streaming_thread.daemon = True
+        self.streaming_thread = threading.Thread(target=self._pump, name="experience-stream", daemon=True)
         self.streaming_thread.start()
-        logger.info("Started experience streaming")
 
     def stop_streaming(self):
         self.stop_event.set()
-        if self.streaming_thread:
-            self.streaming_thread.join(timeout=5)
-        logger.info("Stopped experience streaming")
+        t = self.streaming_thread
+        if t is not None:
+            t.join(timeout=5)
 
-    def _stream_worker(self):
+    def _pump(self):
+        """The stream worker: batches until the source ends or the consumer stops; an error ends the stream (logged), as in
+        the reference (:92-114)."""
         try:
             for batch in self.source:
                 if self.stop_event.is_set():
-                    break
-                self._process_batch(batch)
-        except Exception as e:  # noqa: BLE001 - the reference logs and ends the stream (:111-114)
-            logger.error("Unexpected error in streaming: %s", e)
+                    return
+                self.ingest_batch(batch)
+        except Exception as e:  # noqa: BLE001
+            logger.error("experience stream ended by an error: %s", e)
 
-    def _process_batch(self, batch):
-        """:116-132: statistics, then every experience into the queue without blocking; a full queue drops."""
+    # ---- one batch into the buffer (:116-132) -------------------------------------------------------------------
+    def ingest_batch(self, batch):
         self.stats["total_batches"] += 1
         self.stats["last_batch_time"] = time.time()
         for exp in batch:
-            try:
-                self.experience_queue.put(self._process_experience(exp), block=False)
-                self.stats["total_experiences"] += 1
-            except Exception:  # noqa: BLE001 - queue.Full, like the reference's bare except
-                self.stats["dropped_experiences"] += 1
+            accepted = self.experience_queue.offer(self.as_trainer_dict(exp))
+            self.stats["total_experiences" if accepted else "dropped_experiences"] += 1
 
     @staticmethod
-    def _process_experience(exp) -> Dict[str, Any]:
-        """:134-158 for an experience that already is a dict of arrays: the same keys and types (float32 [9, H, W] tensors,
-        bool mask or None, plain Python scalars)."""
+    def as_trainer_dict(exp) -> Dict[str, Any]:
+        """What `_process_experience` (:134-158) hands a trainer, from an experience that already holds arrays: float32
+        [9, H, W] tensors, a bool mask (None when the message carried none), plain Python scalars."""
         mask = exp.get("action_mask")
-        return {"experience_id": exp["experience_id"], "game_id": exp["game_id"], "player_id": int(exp["player_id"]),
-                "turn": int(exp["turn"]), "state": np.asarray(exp["state"], np.float32), "action": int(exp["action"]),
-                "reward": float(exp["reward"]), "next_state": np.asarray(exp["next_state"], np.float32), "done": bool(exp["done"]),
-                "action_mask": None if mask is None or len(mask) == 0 else np.asarray(mask, np.bool_)}
+        out = {k: exp[k] for k in ("experience_id", "game_id")}
+        out.update(player_id=int(exp["player_id"]), turn=int(exp["turn"]), state=np.asarray(exp["state"], np.float32),
+                   action=int(exp["action"]), reward=float(exp["reward"]), next_state=np.asarray(exp["next_state"], np.float32),
+                   done=bool(exp["done"]), action_mask=(np.asarray(mask, np.bool_) if mask is not None and len(mask) else None))
+        return out
 
+    # ---- the consumer side (:160-185) ---------------------------------------------------------------------------
     def get_experience(self, timeout: float = 1.0) -> Optional[Dict[str, Any]]:
-        try:
-            return self.experience_queue.get(timeout=timeout)
-        except Empty:
-            return None
+        return self.experience_queue.take(timeout)
 
     def get_batch(self, batch_size: int, timeout: float = 5.0) -> List[Dict[str, Any]]:
-        batch = []
-        deadline = time.time() + timeout
-        while len(batch) < batch_size and time.time() < deadline:
-            exp = self.get_experience(timeout=0.1)
-            if exp:
-                batch.append(exp)
-        return batch
+        """Up to batch_size experiences: returns as soon as it has them, or with what arrived when `timeout` runs out."""
+        got, end = [], time.time() + timeout
+        while len(got) < batch_size:
+            left = end - time.time()
+            if left <= 0:
+                break
+            item = self.experience_queue.take(min(left, 0.1))
+            if item is not None:
+                got.append(item)
+        return got
 
     def get_stats(self) -> Dict[str, Any]:
-        return {**self.stats, "queue_size": self.experience_queue.qsize(),
-                "streaming": self.streaming_thread.is_alive() if self.streaming_thread else False}
+        snapshot = dict(self.stats)
+        snapshot["queue_size"] = self.experience_queue.qsize()
+        snapshot["streaming"] = self._streaming()
+        return snapshot
 
 
 class ExperienceDataset:
-    """experience_stream_client.py:188-218: a buffer over the client, sampled without replacement with np.random."""
+    """experience_stream_client.py:188-218: a bounded buffer topped up from the client, sampled without replacement with
+    numpy's global RNG (the same draw as the reference for the same np.random.seed)."""
 
     def __init__(self, client, buffer_size: int = 10000):
-        self.client = client
-        self.buffer = []
-        self.buffer_size = buffer_size
+        self.client, self.buffer_size = client, buffer_size
+        self.buffer: List[Dict[str, Any]] = []
 
     def fill_buffer(self, min_size: int = 1000):
         while len(self.buffer) < min_size:
-            batch = self.client.get_batch(100, timeout=1.0)
-            if not batch:
+            more = self.client.get_batch(100, timeout=1.0)
+            if not more:
                 break
-            self.buffer.extend(batch)
-        if len(self.buffer) > self.buffer_size:
-            self.buffer = self.buffer[-self.buffer_size:]
+            self.buffer += more
+        overflow = len(self.buffer) - self.buffer_size
+        if overflow > 0:
+            del self.buffer[:overflow]                     # the newest buffer_size stay
 
     def sample(self, batch_size: int) -> List[Dict[str, Any]]:
         if len(self.buffer) < batch_size:
             self.fill_buffer(batch_size)
         if len(self.buffer) < batch_size:
-            return self.buffer.copy()
-        indices = np.random.choice(len(self.buffer), batch_size, replace=False)
-        return [self.buffer[i] for i in indices]
+            return list(self.buffer)
+        picks = np.random.choice(len(self.buffer), batch_size, replace=False)
+        return [self.buffer[int(i)] for i in picks]
 
 
 def engine_experience_source(engine, records_per_step, seed=0, max_steps=None, game_id_prefix="vec", invalid_permille=0):

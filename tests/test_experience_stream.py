@@ -35,7 +35,7 @@ def _batches():
 def test_client_flow_matches_the_reference_client():
     client = VecExperienceStreamClient(ExperienceConfig(buffer_size=FLOW["buffer_size"]), lambda cfg: iter(()))
     for b in _batches():
-        client._process_batch(b)
+        client.ingest_batch(b)
     stats = client.get_stats()
     assert {k: stats[k] for k in FLOW["stats"]} == FLOW["stats"] and isinstance(stats["last_batch_time"], float)
     assert set(stats) == {"total_experiences", "total_batches", "dropped_experiences", "last_batch_time", "queue_size", "streaming"}
