@@ -31,6 +31,16 @@ class RolloutStats(C.Structure):
     _fields_ = [("env_steps", C.c_int64), ("aborted_turns", C.c_int64), ("games_finished", C.c_int64), ("reserved", C.c_int64)]
 
 
+class CollectArgs(C.Structure):
+    """gvec_collect_args (include/generals_vec.h): every pointer is device memory."""
+    _fields_ = ([(n, C.c_int32) for n in ("num_envs", "obs_floats", "max_steps_per_episode", "reserved")]
+                + [(n, C.c_int64) for n in ("capacity", "result_capacity")]
+                + [(n, C.c_void_p) for n in ("state", "next_state", "action", "reward", "terminated", "truncated", "was_reset", "needs_reset",
+                                             "ring_state", "ring_next_state", "ring_action", "ring_reward", "ring_done", "ring_counters",
+                                             "episode_reward", "episode_length", "result_reward", "result_length", "result_worker",
+                                             "pool_counters", "scratch")])
+
+
 # every symbol include/generals_vec.h declares: (restype, argtypes)
 _vp, _i32, _u64 = C.c_void_p, C.c_int32, C.c_uint64
 SYMBOLS = {
@@ -74,6 +84,8 @@ SYMBOLS = {
     "gvec_experience_records": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gvec_record_agent_actions": (_i32, [_vp, _i32]),
     "gvec_expand_experience_records": (_i32, [_i32, _vp, C.POINTER(C.c_int32), _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gvec_pool_collect": (_i32, [_i32, _vp, C.POINTER(CollectArgs)]),
+    "gvec_pool_collect_scratch_bytes": (_u64, [_i32]),
     "gvec_gym_observe": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gvec_gym_finish_step": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvec_gym_actions": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1347,6 +1347,32 @@ int32_t gvec_expand_experience_records(int32_t device, void* hip_stream, const i
   return GVEC_OK;
 }
 
+uint64_t gvec_pool_collect_scratch_bytes(int32_t num_envs) { return num_envs > 0 ? pool_collect_scratch_bytes(num_envs) : 0; }
+
+int32_t gvec_pool_collect(int32_t device, void* hip_stream, const gvec_collect_args* a) {
+  if (!a) return GVEC_E_INVALID;
+  if (a->num_envs < 1 || a->obs_floats < 1 || a->max_steps_per_episode < 1 || a->result_capacity < 0 || a->capacity < a->num_envs) {
+    set_err("gvec_pool_collect: num_envs %d, obs_floats %d, max_steps_per_episode %d, capacity %lld (a step's transitions must fit: >= num_envs), "
+            "result_capacity %lld", a->num_envs, a->obs_floats, a->max_steps_per_episode, (long long)a->capacity, (long long)a->result_capacity);
+    return GVEC_E_INVALID;
+  }
+  if (!a->state || !a->next_state || !a->action || !a->reward || !a->terminated || !a->truncated || !a->was_reset || !a->ring_state ||
+      !a->ring_next_state || !a->ring_action || !a->ring_reward || !a->ring_done || !a->ring_counters || !a->episode_reward ||
+      !a->episode_length || !a->pool_counters || !a->scratch ||
+      (a->result_capacity > 0 && (!a->result_reward || !a->result_length || !a->result_worker))) {
+    set_err("gvec_pool_collect: a required pointer is NULL (only needs_reset may be)");
+    return GVEC_E_INVALID;
+  }
+  if (reinterpret_cast<uintptr_t>(a->scratch) & 15) {
+    set_err("gvec_pool_collect: scratch must be 16-byte aligned");
+    return GVEC_E_INVALID;
+  }
+  RET_IF(ensure_device());
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(launch_pool_collect(*a, reinterpret_cast<hipStream_t>(hip_stream)));
+  return GVEC_OK;
+}
+
 int32_t gvec_record_agent_actions(gvec_handle* h, int32_t on) {
   if (!h) return GVEC_E_INVALID;
   if (h->sharded()) {

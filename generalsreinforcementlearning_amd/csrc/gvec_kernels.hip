@@ -1208,6 +1208,200 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pack_updates_kernel(cons
 }
 
 // =========================================================================================
+// pool collection: the loop ParallelEnvPool's workers run around GeneralsEnv.step (python/generals_gym/vector_env.py:164-192)
+// and ReplayBuffer.push (replay_buffer.py:31-36), for every worker at once and without leaving the device
+// =========================================================================================
+// scratch: flag[B] (bit 0 live: this step was a transition of the worker's episode; bit 1 over: the episode ended with it),
+// per 64-worker group the exclusive prefix counts of both bits, the cursors the push works from, what finished episodes report
+struct CollectScratch {
+  uint8_t* flag;          // [G * 64]
+  int32_t* fin_length;    // [B]
+  long long* base_live;   // [G + 1]
+  long long* base_over;   // [G + 1]
+  long long* snap;        // [2]: the ring's cursor and the results held BEFORE this call
+  double* fin_reward;     // [B]
+};
+__host__ __device__ inline int collect_groups(int32_t n) { return (n + 63) >> 6; }
+__host__ __device__ inline CollectScratch collect_scratch(void* base, int32_t n) {
+  const int g = collect_groups(n);
+  CollectScratch c;
+  c.base_live = static_cast<long long*>(base);
+  c.base_over = c.base_live + g + 1;
+  c.snap = c.base_over + g + 1;
+  c.flag = reinterpret_cast<uint8_t*>(c.snap + 2);              // 16 * (g + 2) bytes in: read sixteen bytes at a time
+  c.fin_reward = reinterpret_cast<double*>(c.flag + (size_t)g * 64);
+  c.fin_length = reinterpret_cast<int32_t*>(c.fin_reward + n);
+  return c;
+}
+// one thread per worker: vector_env.py:172-192 without the push
+__global__ __launch_bounds__(256) void collect_flags_kernel(gvec_collect_args A) {
+  const int w = (int)(blockIdx.x * 256 + threadIdx.x);
+  const CollectScratch S = collect_scratch(A.scratch, A.num_envs);
+  if (w >= collect_groups(A.num_envs) * 64) return;
+  if (w >= A.num_envs) {
+    S.flag[w] = 0;          // the tail of the last group
+    return;
+  }
+  const bool live = !A.was_reset[w];
+  const bool done = (A.terminated[w] | A.truncated[w]) != 0;
+  double er = A.episode_reward[w];
+  long long el = A.episode_length[w];
+  if (live) {
+    er += A.reward[w];      // :186
+    el += 1;                // :187
+  }
+  const bool over = live && (done || el >= A.max_steps_per_episode);   // the while condition of :177 failing
+  S.flag[w] = (uint8_t)((live ? 1 : 0) | (over ? 2 : 0));
+  if (over) {
+    S.fin_reward[w] = er;
+    S.fin_length[w] = (int32_t)el;
+    er = 0.0;
+    el = 0;
+    if (!done && A.needs_reset) A.needs_reset[w] = 1;   // cut at the length limit: the next step is the worker's env.reset()
+  }
+  A.episode_reward[w] = er;
+  A.episode_length[w] = el;
+}
+// one workgroup: exclusive prefix counts per 64-worker group (a thread owns a run of consecutive groups, 64 flag bytes each),
+// then the counters move on - the push works from the snapshot
+__global__ __launch_bounds__(1024) void collect_scan_kernel(gvec_collect_args A) {
+  __shared__ long long part[2][1024];
+  const CollectScratch S = collect_scratch(A.scratch, A.num_envs);
+  const int G = collect_groups(A.num_envs);
+  const int tid = (int)threadIdx.x;
+  const int per = (G + 1023) / 1024;
+  const int lo = tid * per < G ? tid * per : G, hi = (lo + per < G) ? lo + per : G;
+  long long nl = 0, no = 0;
+  for (int g = lo; g < hi; ++g) {
+    const uint4* f = reinterpret_cast<const uint4*>(S.flag + (size_t)g * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = f[q];
+      nl += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+      no += __popc(v.x & 0x02020202u) + __popc(v.y & 0x02020202u) + __popc(v.z & 0x02020202u) + __popc(v.w & 0x02020202u);
+    }
+  }
+  part[0][tid] = nl;
+  part[1][tid] = no;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1,024 partial sums, both counts at once
+    const long long a0 = (tid >= off) ? part[0][tid - off] : 0, a1 = (tid >= off) ? part[1][tid - off] : 0;
+    __syncthreads();
+    part[0][tid] += a0;
+    part[1][tid] += a1;
+    __syncthreads();
+  }
+  long long rl = part[0][tid] - nl, ro = part[1][tid] - no;
+  for (int g = lo; g < hi; ++g) {
+    S.base_live[g] = rl;
+    S.base_over[g] = ro;
+    const uint4* f = reinterpret_cast<const uint4*>(S.flag + (size_t)g * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = f[q];
+      rl += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+      ro += __popc(v.x & 0x02020202u) + __popc(v.y & 0x02020202u) + __popc(v.z & 0x02020202u) + __popc(v.w & 0x02020202u);
+    }
+  }
+  if (tid == 1023) {
+    const long long pushed = part[0][1023], ended = part[1][1023];
+    long long* R = reinterpret_cast<long long*>(A.ring_counters);
+    long long* P = reinterpret_cast<long long*>(A.pool_counters);
+    S.snap[0] = R[0];
+    S.snap[1] = P[1];
+    R[0] = (R[0] + pushed) % A.capacity;
+    R[1] = (R[1] + pushed < A.capacity) ? R[1] + pushed : A.capacity;
+    R[2] += pushed;
+    P[0] += ended;
+    const long long room = A.result_capacity - P[1];
+    const long long kept = ended < room ? ended : room;
+    P[1] += kept;
+    P[2] += ended - kept;
+  }
+}
+// A row of n floats from s to d, both only dword-aligned (a row is 9*W*H floats) and not alike: sixteen bytes per lane with
+// BOTH the loads and the stores on 16-byte boundaries - a destination quad is cut out of two neighbouring source quads (the
+// second load hits the lines the neighbouring lane fetches) - because either side misaligned costs a quarter of the rate
+// (4.0-4.2 TB/s against 5.3 on this copy).  The few floats before / after the aligned body go one by one.  `part` of
+// 1 << shift wavefronts share the row.
+template <int D>
+static __device__ __forceinline__ void copy_quads(const float4* __restrict__ sq, float4* __restrict__ dq, int jlo, int jhi, int c, int first, int stride) {
+#pragma unroll 4
+  for (int j = jlo + first; j < jhi; j += stride) {
+    const float4 lo = sq[j + c];
+    float4 o;
+    if (D == 0) {
+      o = lo;
+    } else {
+      const float4 hi = sq[j + c + 1];
+      if (D == 1) o = make_float4(lo.y, lo.z, lo.w, hi.x);
+      if (D == 2) o = make_float4(lo.z, lo.w, hi.x, hi.y);
+      if (D == 3) o = make_float4(lo.w, hi.x, hi.y, hi.z);
+    }
+    dq[j] = o;
+  }
+}
+static __device__ __forceinline__ void copy_row(const float* __restrict__ s, float* __restrict__ d, int n, int part, int lane, int shift) {
+  const int ks = (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(s) & 15u)) & 15u) >> 2);   // floats before s is 16-byte aligned
+  const int kd = (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2);
+  const int delta = uni((kd - ks) & 3), c = kd >= ks ? 0 : -1;
+  // destination quad j = floats [kd + 4j, kd + 4j + 4) = source quads j + c and j + c + 1 (counted from s + ks); all of it inside the row:
+  const int jlo = -c;
+  const int jhi = (n - 8 - ks < 0) ? jlo : (n - 8 - ks) / 4 - c + 1;          // exclusive
+  const float4* sq = reinterpret_cast<const float4*>(s + ks);
+  float4* dq = reinterpret_cast<float4*>(d + kd);
+  const int first = part * 64 + lane, stride = 64 << shift;
+  switch (delta) {
+    case 0: copy_quads<0>(sq, dq, jlo, jhi, c, first, stride); break;
+    case 1: copy_quads<1>(sq, dq, jlo, jhi, c, first, stride); break;
+    case 2: copy_quads<2>(sq, dq, jlo, jhi, c, first, stride); break;
+    default: copy_quads<3>(sq, dq, jlo, jhi, c, first, stride); break;
+  }
+  if (part == 0) {
+    const int head = kd + 4 * jlo, tail = kd + 4 * jhi;       // [0, head) and [tail, n): fewer than 16 floats each
+    if (lane < head && lane < n) d[lane] = s[lane];
+    if (tail + lane < n) d[tail + lane] = s[tail + lane];
+  }
+}
+// `wpe` wavefronts per worker (a power of two): ReplayBuffer.push of its transition, and its episode result
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void collect_push_kernel(gvec_collect_args A, int wpe_shift) {
+  const int gw = uni((int)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+  const int w = gw >> wpe_shift, part = gw & ((1 << wpe_shift) - 1);
+  if (w >= A.num_envs) return;
+  const CollectScratch S = collect_scratch(A.scratch, A.num_envs);
+  const int lane = lane_id();
+  const int g = w >> 6, at = w & 63;
+  const uint32_t mine = S.flag[(size_t)g * 64 + lane];
+  const unsigned long long below = (1ull << at) - 1;
+  const unsigned long long live_m = __ballot(mine & 1), over_m = __ballot(mine & 2);
+  if ((live_m >> at) & 1) {
+    long long slot = S.snap[0] + S.base_live[g] + __popcll(live_m & below);
+    if (slot >= A.capacity) slot -= A.capacity;          // cursor < capacity and fewer than num_envs <= capacity ahead of it
+    const float* s0 = A.state + (size_t)w * A.obs_floats;
+    const float* s1 = A.next_state + (size_t)w * A.obs_floats;
+    float* d0 = A.ring_state + (size_t)slot * A.obs_floats;
+    float* d1 = A.ring_next_state + (size_t)slot * A.obs_floats;
+    copy_row(s0, d0, A.obs_floats, part, lane, wpe_shift);
+    copy_row(s1, d1, A.obs_floats, part, lane, wpe_shift);
+    if (part == 0) {
+      if (lane == 0) {
+        A.ring_action[slot] = A.action[w];
+        A.ring_reward[slot] = A.reward[w];
+        A.ring_done[slot] = (A.terminated[w] | A.truncated[w]) != 0;
+      }
+    }
+  }
+  if (part == 0 && lane == 0 && ((over_m >> at) & 1)) {
+    const long long j = S.snap[1] + S.base_over[g] + __popcll(over_m & below);
+    if (j < A.result_capacity) {
+      A.result_reward[j] = S.fin_reward[w];
+      A.result_length[j] = S.fin_length[w];
+      A.result_worker[j] = w;
+    }
+  }
+}
+
+// =========================================================================================
 // import: planes -> resident record (gvec_reset / gvec_write_state / pool build)
 // =========================================================================================
 template <int MAXP, int NSLOT>
@@ -1904,6 +2098,19 @@ hipError_t launch_pack_updates(const unsigned long long* rows, const int32_t* co
                                int32_t cap, long long capacity, hipStream_t s) {
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, count, offset, n);
   hipLaunchKernelGGL(pack_updates_kernel, wave_grid(n), dim3(64 * WAVES_PER_BLOCK), 0, s, rows, count, offset, packed, n, cap, capacity);
+  return hipGetLastError();
+}
+size_t pool_collect_scratch_bytes(int32_t n) {
+  const size_t g = (size_t)collect_groups(n);
+  return (2 * (g + 1) + 2) * 8 + (size_t)n * 8 + (size_t)n * 4 + g * 64;
+}
+hipError_t launch_pool_collect(const gvec_collect_args& a, hipStream_t s) {
+  const int padded = collect_groups(a.num_envs) * 64;
+  hipLaunchKernelGGL(collect_flags_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(collect_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+  int shift = 0;                                   // enough wavefronts to fill 256 CUs when there are few workers
+  while (shift < 3 && ((long long)a.num_envs << shift) < 16384) ++shift;
+  hipLaunchKernelGGL(collect_push_kernel, wave_grid(a.num_envs << shift), dim3(64 * WAVES_PER_BLOCK), 0, s, a, shift);
   return hipGetLastError();
 }
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s) {

@@ -206,6 +206,9 @@ hipError_t launch_pack_updates(const unsigned long long* rows, const int32_t* co
 // the consumer side of the record exchange: layout8 as gvec_experience_record_layout fills it
 hipError_t launch_expand_records(const void* records, int32_t n, const int32_t* layout8, float* state, float* next_state, uint8_t* mask,
                                  int32_t* meta, hipStream_t s);
+// gvec_pool_collect: ParallelEnvPool._run_episode's bookkeeping + ReplayBuffer.push for every worker (generals_vec.h)
+hipError_t launch_pool_collect(const gvec_collect_args& a, hipStream_t s);
+size_t pool_collect_scratch_bytes(int32_t num_envs);
 hipError_t launch_gym_step(const Variant& v, const StepArgs& a, const GymStepArgs& g, hipStream_t s);
 hipError_t launch_gym_observe(const Variant& v, const GymArgs& a, hipStream_t s);
 hipError_t launch_gym_actions(const GymActArgs& a, hipStream_t s);

@@ -15,6 +15,9 @@ What differs, by construction of a vector env:
   * an episode that ends (terminated / truncated, or cut at `max_steps_per_episode` - the pool then asks the env to
     re-deal that board with `force_reset`) starts its successor on the env's next step, which returns the new episode's
     first observation with info["reset"] set; that step is the worker's `env.reset()` and is not a transition;
+  * with a `DeviceReplayBuffer` (and `GeneralsVecEnv(device_outputs=True)`, `batched_actions=True`) the whole loop is
+    resident on the GPU: `action_fn(states, valid_masks, None, torch_generator) -> CUDA int64 actions[num_envs]`, transitions
+    appended to the ring in HBM and episode results logged by `gvec_pool_collect` - the host only enqueues launches;
   * `batched_actions=True`: `action_fn(states[k], valid_masks[k], worker_ids[k], rngs) -> actions[k]` for the k workers
     that play this step (rngs: the list of all workers' RNGs, indexed by worker id) - one policy forward for all envs;
     the default keeps the reference's per-env signature `(state, valid_mask, worker_id, rng) -> int`
@@ -110,15 +113,174 @@ class ReplayBuffer:
             return self._size
 
 
+class DeviceReplayBuffer:
+    """The replay ring resident in HBM: what `ReplayBuffer` is to a host collector, for a pool that never leaves the GPU
+    (`ParallelVecEnvPool` over a `GeneralsVecEnv(device_outputs=True)`).  Transitions are appended by `gvec_pool_collect`
+    (one wavefront moves one row) straight from the gym kernel's output buffers; `sample_arrays` gathers a batch into CUDA
+    tensors a learner consumes in place.  288 GB of HBM hold 17 million 15x15 transitions (2 x 8,100 B of observation each).
+    Same semantics as replay_buffer.py:13-55 - the oldest transition is overwritten once `capacity` is reached, `sample`
+    draws uniformly without replacement and raises ValueError when fewer than batch_size are held, `total_pushed` counts
+    every push - with one difference: the draw comes from a torch generator on the device, not from `random`."""
+
+    def __init__(self, capacity, device=0):
+        if capacity <= 0:
+            raise ValueError(f"capacity must be positive, got {capacity}")
+        import torch
+        self._t = torch
+        self.capacity = int(capacity)
+        self.device = torch.device("cuda", device)
+        self.counters = torch.zeros(4, dtype=torch.int64, device=self.device)     # cursor, size, total pushed, 0
+        self.state = self.next_state = self.action = self.reward = self.done = None
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(0)
+        self._guard = threading.Lock()
+
+    def allocate(self, obs_shape):
+        """The five slabs of the ring (at the first push; a collector calls it with the env's observation shape)."""
+        if self.state is None:
+            t, dev, cap = self._t, self.device, self.capacity
+            self.obs_shape = tuple(obs_shape)
+            self.state = t.empty((cap,) + self.obs_shape, dtype=t.float32, device=dev)
+            self.next_state = t.empty((cap,) + self.obs_shape, dtype=t.float32, device=dev)
+            self.action = t.empty(cap, dtype=t.int64, device=dev)
+            self.reward = t.empty(cap, dtype=t.float64, device=dev)
+            self.done = t.empty(cap, dtype=t.bool, device=dev)
+        return self
+
+    def manual_seed(self, seed):
+        self._gen.manual_seed(int(seed))
+
+    def push_batch(self, states, actions, rewards, next_states, dones):
+        """k transitions in order, for a learner that pushes by itself (the pool appends through gvec_pool_collect)."""
+        t = self._t
+        dev = self.device
+        actions = t.as_tensor(actions, dtype=t.int64, device=dev).reshape(-1)
+        k = int(actions.numel())
+        if k == 0:
+            return
+        states = t.as_tensor(states, dtype=t.float32, device=dev)
+        next_states = t.as_tensor(next_states, dtype=t.float32, device=dev)
+        with self._guard:
+            self.allocate(states.shape[1:])
+            cursor, size, pushed = (int(v) for v in self.counters[:3].tolist())
+            lo = max(0, k - self.capacity)                                    # only the last `capacity` survive, as with k pushes
+            idx = (cursor + t.arange(lo, k, device=dev)) % self.capacity
+            self.state[idx], self.next_state[idx] = states[lo:], next_states[lo:]
+            self.action[idx] = actions[lo:]
+            self.reward[idx] = t.as_tensor(rewards, dtype=t.float64, device=dev).reshape(-1)[lo:]
+            self.done[idx] = t.as_tensor(dones, dtype=t.bool, device=dev).reshape(-1)[lo:]
+            self.counters[:3] = t.tensor([(cursor + k) % self.capacity, min(size + k, self.capacity), pushed + k], dtype=t.int64)
+
+    def push(self, state, action, reward, next_state, done):
+        t = self._t
+        self.push_batch(t.as_tensor(state)[None], [action], [reward], t.as_tensor(next_state)[None], [done])
+
+    def sample_indices(self, batch_size):
+        """batch_size distinct slots, uniformly over the transitions held (random.sample's contract, replay_buffer.py:40-43)."""
+        t = self._t
+        size = len(self)
+        if batch_size > size or batch_size < 0:
+            raise ValueError("Sample larger than population or is negative")          # random.sample's own words
+        if size <= (1 << 16) or 4 * batch_size >= size:
+            return t.randperm(size, device=self.device, generator=self._gen)[:batch_size]
+        got = t.empty(0, dtype=t.int64, device=self.device)                            # big ring, small batch: draw, drop repeats, top up
+        while got.numel() < batch_size:
+            draw = t.randint(size, (2 * (batch_size - got.numel()) + 16,), device=self.device, generator=self._gen)
+            both = t.cat([got, draw])
+            uniq, inverse = t.unique(both, return_inverse=True)
+            first = t.full((uniq.numel(),), both.numel(), dtype=t.int64, device=self.device).scatter_reduce_(
+                0, inverse, t.arange(both.numel(), device=self.device), reduce="amin")
+            got = both[first.sort().values]                                            # first occurrences, in drawing order
+        return got[:batch_size]
+
+    def sample_arrays(self, batch_size):
+        """(states, actions, rewards, next_states, dones) as CUDA tensors."""
+        idx = self.sample_indices(batch_size)
+        return self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx], self.done[idx]
+
+    def sample(self, batch_size):
+        """The reference's return type - a list of (state, action, reward, next_state, done) tuples - on the host."""
+        s, a, r, n, d = (x.cpu().numpy() for x in self.sample_arrays(batch_size))
+        return [(s[i], int(a[i]), float(r[i]), n[i], bool(d[i])) for i in range(len(a))]
+
+    @property
+    def total_pushed(self):
+        return int(self.counters[2])
+
+    def __len__(self):
+        return int(self.counters[1])
+
+
+class _DeviceCollector:
+    """The device-side state of a pool whose env, policy and buffer all live on the GPU, and the one call per vector step
+    that advances it (gvec_pool_collect)."""
+
+    def __init__(self, env, buffer, max_steps_per_episode, result_capacity):
+        import ctypes
+        import torch
+        from ._lib import CollectArgs, check
+        self._C, self._t, self._check = ctypes, torch, check
+        self.env, self.buffer = env, buffer
+        self.L = env.engine.L
+        dev = env._dev
+        if buffer.device != dev:
+            raise ValueError(f"replay buffer on {buffer.device}, env on {dev}")
+        if buffer.capacity < env.num_envs:
+            raise ValueError(f"a DeviceReplayBuffer must hold at least one vector step: capacity {buffer.capacity} < {env.num_envs} envs")
+        buffer.allocate(env.single_observation_shape)
+        n = env.num_envs
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.episode_reward, self.episode_length = z(n, torch.float64), z(n, torch.int64)
+        self.result_capacity = int(result_capacity)
+        self.result_reward, self.result_length, self.result_worker = (z(self.result_capacity, torch.float64), z(self.result_capacity, torch.int32),
+                                                                      z(self.result_capacity, torch.int32))
+        self.counters = z(4, torch.int64)          # episodes, results held, results dropped, 0
+        self.scratch = z((int(self.L.gvec_pool_collect_scratch_bytes(n)) + 7) // 8, torch.int64)
+        a = self.args = CollectArgs()
+        a.num_envs, a.obs_floats, a.max_steps_per_episode = n, int(np.prod(env.single_observation_shape)), int(max_steps_per_episode)
+        a.capacity, a.result_capacity = buffer.capacity, self.result_capacity
+        for name, tensor in (("ring_state", buffer.state), ("ring_next_state", buffer.next_state), ("ring_action", buffer.action),
+                             ("ring_reward", buffer.reward), ("ring_done", buffer.done), ("ring_counters", buffer.counters),
+                             ("episode_reward", self.episode_reward), ("episode_length", self.episode_length),
+                             ("result_reward", self.result_reward), ("result_length", self.result_length), ("result_worker", self.result_worker),
+                             ("pool_counters", self.counters), ("scratch", self.scratch)):
+            setattr(a, name, tensor.data_ptr())
+        self._device_index = dev.index
+
+    def restart(self):
+        self.episode_reward.zero_()
+        self.episode_length.zero_()
+
+    def collect(self, state, actions, next_state, reward, terminated, truncated, was_reset, needs_reset):
+        a = self.args
+        a.state, a.next_state, a.action, a.reward = state.data_ptr(), next_state.data_ptr(), actions.data_ptr(), reward.data_ptr()
+        a.terminated, a.truncated, a.was_reset, a.needs_reset = terminated.data_ptr(), truncated.data_ptr(), was_reset.data_ptr(), needs_reset.data_ptr()
+        stream = self._t.cuda.current_stream(self.env._dev).cuda_stream
+        self._check(self.L.gvec_pool_collect(self._device_index, stream, self._C.byref(a)), "gvec_pool_collect")
+
+    def pop_results(self):
+        held = int(self.counters[1])
+        if held == 0:
+            return []
+        r, l, w = self.result_reward[:held].tolist(), self.result_length[:held].tolist(), self.result_worker[:held].tolist()
+        self.counters[1] = 0
+        return list(zip(r, l, w))
+
+
 class ParallelVecEnvPool:
     """vector_env.py:28-192 over a vector env; see the module docstring for what is kept and what differs."""
 
     def __init__(self, num_envs, env_factory, action_fn, replay_buffer, max_steps_per_episode=200, max_env_retries=3, seed=42,
-                 batched_actions=False, retry_sleep_s=2.0):
+                 batched_actions=False, retry_sleep_s=2.0, result_capacity=1 << 20):
         # the reference's public attributes (vector_env.py:45-51)
         (self.num_envs, self.env_factory, self.action_fn, self.replay_buffer, self.max_steps_per_episode, self.max_env_retries,
          self.seed) = num_envs, env_factory, action_fn, replay_buffer, max_steps_per_episode, max_env_retries, seed
         self.batched_actions, self.retry_sleep_s = bool(batched_actions), retry_sleep_s
+        # a DeviceReplayBuffer switches the pool to its resident form: env (device_outputs), policy and ring on the GPU
+        self.on_device = isinstance(replay_buffer, DeviceReplayBuffer)
+        self.result_capacity = int(result_capacity)
+        self._dc = None
+        self._step_lock = threading.Lock()      # device form: a vector step's launches vs. a reader of the result log
         # one collector instead of one thread per env
         self._halt = threading.Event()
         self._collector = None
@@ -162,6 +324,8 @@ class ParallelVecEnvPool:
 
     @property
     def total_episodes(self):
+        if self._dc is not None:
+            return int(self._dc.counters[0])
         with self._tally:
             return self._episodes_done
 
@@ -172,6 +336,9 @@ class ParallelVecEnvPool:
 
     def pop_episode_results(self):
         """Finished-episode results since the last call, oldest first."""
+        if self._dc is not None:
+            with self._step_lock:               # between two vector steps: the log is read and emptied in stream order
+                return self._dc.pop_results()
         with self._tally:
             out, self._finished = self._finished, []
         return out
@@ -203,6 +370,16 @@ class ParallelVecEnvPool:
         """Every worker's first `env.reset()` (vector_env.py:166-167)."""
         self._state, info = self._env.reset()
         self._mask = info.get("valid_actions_mask")
+        if self.on_device:
+            if not getattr(self._env, "device_outputs", False) or not self.batched_actions:
+                raise ValueError("a DeviceReplayBuffer needs a vector env with device_outputs=True and batched_actions=True")
+            if self._dc is None or self._dc.env is not self._env:
+                self._dc = _DeviceCollector(self._env, self.replay_buffer, self.max_steps_per_episode, self.result_capacity)
+                import torch
+                self._generator = torch.Generator(device=self._env._dev)
+                self._generator.manual_seed(self.seed)
+            self._dc.restart()
+            return
         if self._mask is None:
             self._mask = np.ones((self.num_envs, self._env.single_action_n), bool)
         self._ep_reward[:] = 0.0
@@ -225,6 +402,8 @@ class ParallelVecEnvPool:
 
     def _collect_step(self):
         """One vector step = one iteration of every worker's `_run_episode` loop (vector_env.py:172-192)."""
+        if self.on_device:
+            return self._collect_step_device()
         state = self._state
         actions = self._actions()
         next_state, reward, terminated, truncated, info = self._env.step(actions)
@@ -256,6 +435,20 @@ class ParallelVecEnvPool:
         self._state = next_state
         m = info.get("valid_actions_mask")
         self._mask = m if m is not None else np.ones((self.num_envs, self._env.single_action_n), bool)
+
+    def _collect_step_device(self):
+        """The same iteration with nothing on the host: the policy maps CUDA tensors to a CUDA int64 tensor of actions (it is
+        asked for every worker; what it answers for a worker whose step is its `env.reset()` is ignored by the env), the gym
+        kernel plays the step, gvec_pool_collect appends the transitions to the ring, keeps the episode accumulators, logs
+        finished episodes and raises the env's needs_reset for episodes cut at `max_steps_per_episode`.  No synchronisation:
+        the host only enqueues."""
+        env = self._env
+        with self._step_lock:
+            state = self._state
+            actions = self.action_fn(state, self._mask, None, self._generator)
+            next_state, reward, terminated, truncated, info = env.step(actions)
+            self._dc.collect(state, env.last_actions, next_state, reward, terminated, truncated, info["reset"], env.needs_reset_buffer())
+            self._state, self._mask = next_state, info["valid_actions_mask"]
 
     def collect(self, steps):
         """Synchronous form for trainers and tests that own the loop: `steps` vector steps in the caller's thread."""

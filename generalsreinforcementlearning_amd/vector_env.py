@@ -127,6 +127,7 @@ class GeneralsVecEnv:
             if isinstance(actions, np.ndarray):
                 actions = t.from_numpy(np.ascontiguousarray(actions, np.int64))
             actions = t.as_tensor(actions, dtype=t.int64).to(self._dev).reshape(self.num_envs).contiguous()
+        self.last_actions = actions        # the tensor the launch reads (kept alive; a collector records it)
         k = self._step_no
         self._step_no += 1
         self._obs_flip ^= 1
@@ -172,8 +173,16 @@ class GeneralsVecEnv:
         exactly as if that step had been preceded by terminated / truncated.  How a collector cuts an episode at its own
         length limit (ParallelEnvPool.max_steps_per_episode, vector_env.py:177) without a per-env reset() call."""
         t = self._t
-        m = t.as_tensor(np.asarray(env_mask.cpu() if hasattr(env_mask, "cpu") else env_mask, bool)).to(self._dev)
-        self._d_step[self._step_no % 3]["needs_reset"] |= m
+        if isinstance(env_mask, t.Tensor):
+            m = env_mask.to(device=self._dev, dtype=t.bool)        # a CUDA mask stays on the device: no synchronisation
+        else:
+            m = t.as_tensor(np.asarray(env_mask, bool)).to(self._dev)
+        self.needs_reset_buffer().logical_or_(m)
+
+    def needs_reset_buffer(self):
+        """The bool[num_envs] CUDA tensor the NEXT step reads as `resetting` (written by the last step: terminated |
+        truncated).  A device-side collector raises entries of it to cut episodes (gvec_pool_collect)."""
+        return self._d_step[self._step_no % 3]["needs_reset"]
 
     def close(self):
         self.engine.close()

@@ -447,6 +447,39 @@ int32_t gvec_gym_step(gvec_handle* h, int32_t player, uint64_t agent_seed, const
                       uint8_t* truncated, int8_t* winner, uint8_t* needs_reset, int64_t* turn_out, uint8_t* played,
                       uint8_t* invalid, uint8_t* error);
 
+/* The collection loop around GeneralsEnv.step, resident on the device: one iteration of every worker's
+ * ParallelEnvPool._run_episode (python/generals_gym/vector_env.py:164-192) plus ReplayBuffer.push
+ * (python/generals_gym/replay_buffer.py:31-36) for num_envs workers, on the outputs of one gvec_gym_step, without a byte
+ * crossing PCIe.  Per worker w, with live = !was_reset[w] (this step was not the worker's env.reset()):
+ *   live:  the transition (state[w], action[w], reward[w], next_state[w], terminated[w] | truncated[w]) goes to the ring
+ *          (workers in ascending order from the ring's cursor; the oldest transitions are overwritten once `capacity` is
+ *          reached - deque(maxlen) semantics); episode_reward[w] += reward[w]; episode_length[w] += 1;
+ *   over = live & (done | episode_length[w] >= max_steps_per_episode): (episode_reward, episode_length, w) is appended
+ *          to the result log (vector_env.py:189-190; entries beyond result_capacity are counted, not kept), the two
+ *          accumulators are zeroed, and needs_reset[w] is raised when the episode was cut at the length limit (so that
+ *          the NEXT gvec_gym_step re-deals the env - the worker's next env.reset()).
+ * ring_counters[4]  = {cursor, size, total pushed, 0};  pool_counters[4] = {episodes, results held, results dropped, 0}
+ * (int64, device memory; zero them to start; "results held" is reset by the consumer after it has read the log).
+ * scratch: gvec_pool_collect_scratch_bytes(num_envs) bytes, 16-byte aligned, contents of no interest to the caller.  Every
+ * pointer is device memory on `device`; capacity >= num_envs.  Three launches on hip_stream: per-worker flags, one
+ * workgroup's prefix counts (which also moves the counters on), the copy (a row of the ring is obs_floats floats, moved
+ * by one to eight wavefronts). */
+typedef struct gvec_collect_args {
+  int32_t num_envs, obs_floats, max_steps_per_episode, reserved;
+  int64_t capacity, result_capacity;
+  const float* state; const float* next_state; const int64_t* action; const double* reward;
+  const uint8_t* terminated; const uint8_t* truncated; const uint8_t* was_reset;
+  uint8_t* needs_reset;
+  float* ring_state; float* ring_next_state; int64_t* ring_action; double* ring_reward; uint8_t* ring_done;
+  int64_t* ring_counters;
+  double* episode_reward; int64_t* episode_length;
+  double* result_reward; int32_t* result_length; int32_t* result_worker;
+  int64_t* pool_counters;
+  void* scratch;
+} gvec_collect_args;
+int32_t gvec_pool_collect(int32_t device, void* hip_stream, const gvec_collect_args* args);
+uint64_t gvec_pool_collect_scratch_bytes(int32_t num_envs);
+
 /* ---- experience gather support ---------------------------------------
  * Writes the compact state records of envs [env_begin, env_begin+n) into a device
  * buffer (e.g. a torch tensor handed to RCCL) as a slab [n] headers | [n] plane blocks |
