@@ -78,12 +78,17 @@ class ReplayBuffer:
         with self._guard:
             if self._state is None:
                 self._alloc(states[0])
-            idx = (self._cursor + np.arange(k)) % self.capacity
+            first = self._cursor
             if k > self.capacity:                                            # only the last `capacity` survive, as with k pushes
                 keep = slice(k - self.capacity, k)
-                idx, states, actions, rewards, next_states, dones = idx[keep], states[keep], actions[keep], rewards[keep], next_states[keep], dones[keep]
-            self._state[idx], self._next[idx] = states, next_states
-            self._action[idx], self._reward[idx], self._done[idx] = actions, rewards, dones
+                first = (first + k - self.capacity) % self.capacity
+                states, actions, rewards, next_states, dones = states[keep], actions[keep], rewards[keep], next_states[keep], dones[keep]
+            n = len(actions)
+            head = min(n, self.capacity - first)                             # two contiguous runs (the ring wraps at most once): memcpy, not a gather
+            for dst, src in ((self._state, states), (self._next, next_states), (self._action, actions), (self._reward, rewards), (self._done, dones)):
+                dst[first:first + head] = src[:head]
+                if head < n:
+                    dst[:n - head] = src[head:]
             self._cursor = (self._cursor + k) % self.capacity
             self._size = min(self._size + k, self.capacity)
             self._pushed += k
@@ -414,7 +419,10 @@ class ParallelVecEnvPool:
         idx = np.flatnonzero(live)
         if len(idx):
             if hasattr(self.replay_buffer, "push_batch"):
-                self.replay_buffer.push_batch(np.array(state[idx]), actions[idx], reward[idx], np.array(next_state[idx]), done[idx])
+                if len(idx) == self.num_envs:        # the usual step: no worker is re-dealing, nothing to pick out (push_batch copies)
+                    self.replay_buffer.push_batch(state, actions, reward, next_state, done)
+                else:
+                    self.replay_buffer.push_batch(state[idx], actions[idx], reward[idx], next_state[idx], done[idx])
             else:
                 for w in idx:
                     self.replay_buffer.push(np.array(state[w]), int(actions[w]), float(reward[w]), np.array(next_state[w]), bool(done[w]))

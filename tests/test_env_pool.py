@@ -369,3 +369,24 @@ def test_device_pool_thread_runs_and_stops():
     assert pool.alive_workers == 0 and pool.total_episodes == len(seen) >= 4 * B
     assert pool.total_env_steps == buf.total_pushed == sum(l for _, l, _ in seen) + int(pool._dc.episode_length.sum())
     assert {w for _, _, w in seen} == set(range(B)) and max(l for _, l, _ in seen) <= 25
+
+
+def test_push_batch_is_k_pushes():
+    """Every (capacity, batch sizes) case: the ring after push_batch calls equals the ring after the same transitions pushed
+    one by one - runs that fit, runs that wrap, and batches larger than the ring."""
+    rng = np.random.default_rng(4)
+    for cap, sizes in ((7, [3, 3, 3, 7, 1, 20, 2]), (5, [5, 5]), (16, [1, 30, 16, 15, 2]), (3, [10])):
+        one, many, t = ReplayBuffer(cap), ReplayBuffer(cap), 0
+        for k in sizes:
+            s = rng.random((k, 2, 3), dtype=np.float32)
+            ns = rng.random((k, 2, 3), dtype=np.float32)
+            a, r, d = np.arange(t, t + k), rng.random(k), rng.random(k) < 0.3
+            t += k
+            many.push_batch(s, a, r, ns, d)
+            for i in range(k):
+                one.push(s[i], int(a[i]), float(r[i]), ns[i], bool(d[i]))
+            assert (many._cursor, many._size, many._pushed) == (one._cursor, one._size, one._pushed)
+            n = one._size
+            order = (one._cursor - n + np.arange(n)) % cap if n == cap else np.arange(n)
+            for f in ("_state", "_next", "_action", "_reward", "_done"):
+                assert np.array_equal(getattr(many, f)[order], getattr(one, f)[order]), (cap, k, f)
