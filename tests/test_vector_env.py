@@ -415,8 +415,10 @@ def test_gym_observation_log_channel_is_numpys_float64_log():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,P,fog", [(9, 8, 2, True), (20, 20, 4, True), (12, 13, 3, False), (25, 25, 4, True), (32, 32, 8, True)],
-                         ids=["9x8_p2", "20x20_p4", "12x13_p3_nofog", "25x25_p4", "32x32_p8"])
+@pytest.mark.parametrize("w,h,P,fog", [(9, 8, 2, True), (20, 20, 4, True), (12, 13, 3, False), (25, 25, 4, True), (32, 32, 8, True),
+                                       (5, 5, 2, True), (16, 16, 2, True), (21, 21, 8, True), (25, 24, 8, False), (30, 32, 2, True), (11, 11, 4, True)],
+                         ids=["9x8_p2", "20x20_p4", "12x13_p3_nofog", "25x25_p4", "32x32_p8", "5x5_p2", "16x16_p2", "21x21_p8", "25x24_p8_nofog",
+                              "30x32_p2", "11x11_p4"])
 def test_gym_step_equals_the_four_call_composition(w, h, P, fog):
     """gvec_gym_step (ONE launch) == gvec_agent_actions -> gvec_gym_actions -> gvec_step -> gvec_gym_finish_step on a twin
     engine: every output of every step bit for bit, and the two engines' states at the end - over every register layout of
