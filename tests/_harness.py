@@ -57,3 +57,22 @@ def run_lockstep(eng, ora, turns, seed, invalid_permille=0, check_every=1, want_
         assert np.array_equal(herr, oerr), f"{ctx} turn {k}: err differs: envs {np.argwhere(herr != oerr)[:8].ravel()} hip={herr[herr != oerr][:8]} ora={oerr[herr != oerr][:8]}"
         if (k + 1) % check_every == 0 or k == turns - 1:
             assert_states_equal(eng.game_state(), ora.read_state(), f"{ctx} after turn {k + 1}")
+
+
+# Every compiled instantiation of the kernels: <max players 2 / 4 / 8> x <1, 2, 4, 7, 10, 16 slots of 64 tiles> x <odd / even
+# number of plane dwords> (gvec_kernels.hip dispatch, launch_step).  The board limits below select each <slots, parity>.
+VARIANT_DIMS = {(1, "odd"): (5, 5), (1, "even"): (8, 8), (2, "odd"): (9, 10), (2, "even"): (11, 11), (4, "odd"): (14, 15),
+                (4, "even"): (16, 16), (7, "odd"): (20, 20), (7, "even"): (21, 21), (10, "odd"): (24, 25), (10, "even"): (25, 25),
+                (16, "odd"): (30, 32), (16, "even"): (32, 32)}
+VARIANT_IDS = [f"slots{s}_{o}" for s, o in sorted(VARIANT_DIMS)]
+
+
+def variant_batch(maxp, slots, parity, B):
+    """(max_w, max_h, per-env (w, h, players)) of a ragged batch on the limits that select the variant: the variant follows
+    the handle's player limit; a small board takes as many generals as the generator can space out."""
+    mw, mh = VARIANT_DIMS[(slots, parity)]
+    assert (mw * mh + 63) // 64 <= slots and (slots == 1 or mw * mh > {2: 64, 4: 128, 7: 256, 10: 448, 16: 640}[slots])
+    players = {2: [2], 4: [3, 4], 8: [5, 8, 6]}[maxp]
+    small = (max(3, mw - 3), max(3, mh - 2))
+    dims = [(mw, mh) if i % 3 else small for i in range(B)]
+    return mw, mh, [d + (min(players[i % len(players)], max(2, d[0] * d[1] // 30)),) for i, d in enumerate(dims)]

@@ -362,3 +362,58 @@ def test_expand_records_rejects_what_is_not_a_layout_and_ignores_malformed_recor
     junk[:, 2] = 0xFF
     ex = expand_records_device(junk, lay)
     assert len(ex["env"]) == 0
+
+
+@pytest.mark.parametrize("maxp", [2, 4, 8])
+@pytest.mark.parametrize("slots,parity", sorted(H.VARIANT_DIMS), ids=H.VARIANT_IDS)
+def test_experience_channel_on_every_kernel_variant(g, maxp, slots, parity):
+    """Rewards every turn, StateToTensor / GenerateActionMask for every player, the compact records byte for byte, and their
+    expansion on the device - on the board limits that select each compiled <players, slots, parity> instantiation."""
+    import torch
+    import _records as R
+    from generalsreinforcementlearning_amd.experience import decode_records, expand_records_device
+    B = 12
+    mw, mh, sizes = H.variant_batch(maxp, slots, parity, B)
+    army, owner, typ, w, h, p = H.gen_boards(500 + slots, sizes, mw, mh)
+    eng = g.VecEngine(B, mw, mh, maxp, fog_of_war=True)
+    ora = O.OracleBatch(B, mw, mh, maxp, fog=True)
+    eng.reset(army, owner, typ, w, h, p)
+    ora.reset(army, owner, typ, w, h, p)
+    t0 = (18 + np.arange(B) % 7).astype(np.int32)            # the growth turn (25) falls inside the run
+    eng.write_state({"turn": t0})
+    ora.write_state({"turn": t0})
+    lay = eng.experience_record_layout()
+    assert lay == R.layout_for(mw, mh, maxp)
+    slab = torch.zeros(B * lay["record_dw"], dtype=torch.int32, device="cuda")
+    ctx = f"<{maxp},{slots},{parity}>"
+    for k in range(12):
+        acts = ora.agent_actions(41, 10)
+        snap = R.capture(ora)
+        eng.experience_begin()
+        ora.experience_begin()
+        assert np.array_equal(eng.step(acts), ora.step(acts))
+        hr, hd = eng.experience_rewards()
+        orr, od = ora.rewards()
+        assert np.array_equal(hr.view(np.uint32), orr.view(np.uint32)) and np.array_equal(hd, od.astype(bool)), (ctx, k)
+        eng.experience_records(slab.data_ptr(), actions=acts, env_id_base=7)
+        eng.synchronize()
+        got = slab.cpu().numpy().view(np.uint32).reshape(B, lay["record_dw"])
+        want = R.encode(ora, snap, acts, lay, env_id_base=7)
+        assert np.array_equal(got, want), (ctx, k, np.unique(np.argwhere(got != want)[:, 0])[:6])
+        if k % 4 == 3:
+            assert np.array_equal(eng.serializer_mask_bits(), ora.serializer_mask()), (ctx, k)
+            for player in range(maxp):
+                assert np.array_equal(eng.observe(player).view(np.uint32), ora.observe(player).view(np.uint32)), (ctx, k, player)
+            dec = decode_records(got, lay)
+            ex = expand_records_device(slab, lay)
+            assert len(ex["env"]) == len(dec["env"]) > 0
+            for f in ("env", "player_id", "turn", "action", "done", "width", "height"):
+                assert np.array_equal(ex[f].cpu().numpy(), np.asarray(dec[f])), (ctx, k, f)
+            assert np.array_equal(ex["reward"].cpu().numpy().view(np.uint32), dec["reward"].view(np.uint32))
+            xs, xn, xm = ex["state"].cpu().numpy(), ex["next_state"].cpu().numpy(), ex["action_mask"].cpu().numpy()
+            for i in range(len(dec["env"])):
+                hw = int(dec["width"][i]) * int(dec["height"][i])
+                for a, b in ((xs[i], dec["state"][i]), (xn[i], dec["next_state"][i])):
+                    assert np.array_equal(a[: 9 * hw].view(np.uint32), np.asarray(b).reshape(-1).view(np.uint32)) and not a[9 * hw:].any(), (ctx, k, i)
+                assert np.array_equal(xm[i][: 4 * hw], dec["action_mask"][i]) and not xm[i][4 * hw:].any()
+    H.assert_states_equal(eng.game_state(), ora.read_state(), ctx)

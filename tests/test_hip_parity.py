@@ -474,26 +474,13 @@ def test_full_size_subset_and_invariants(g, B, w, h, p, fog):
 
 
 # ------------------------------------------------------------------ every compiled variant of the kernels
-# <max players 2 / 4 / 8> x <1, 2, 4, 7, 10, 16 slots of 64 tiles> x <odd / even number of plane dwords> (gvec_kernels.hip
-# dispatch, launch_step): the board limits below select each one; players vary inside the batch.
-_VARIANT_DIMS = {(1, "odd"): (5, 5), (1, "even"): (8, 8), (2, "odd"): (9, 10), (2, "even"): (11, 11), (4, "odd"): (14, 15),
-                 (4, "even"): (16, 16), (7, "odd"): (20, 20), (7, "even"): (21, 21), (10, "odd"): (24, 25), (10, "even"): (25, 25),
-                 (16, "odd"): (30, 32), (16, "even"): (32, 32)}
-
-
 @pytest.mark.parametrize("maxp", [2, 4, 8])
-@pytest.mark.parametrize("slots,parity", sorted(_VARIANT_DIMS), ids=[f"slots{s}_{o}" for s, o in sorted(_VARIANT_DIMS)])
+@pytest.mark.parametrize("slots,parity", sorted(H.VARIANT_DIMS), ids=H.VARIANT_IDS)
 def test_every_kernel_variant_against_the_oracle(g, maxp, slots, parity):
     """Per-turn lock-step (host actions, masks, err codes every turn), then the device agent's per-turn and fused rollouts
-    with auto-reset, on the board limits that select this <players, slots, parity> instantiation."""
-    mw, mh = _VARIANT_DIMS[(slots, parity)]
-    assert (mw * mh + 63) // 64 <= slots and (slots == 1 or mw * mh > {2: 64, 4: 128, 7: 256, 10: 448, 16: 640}[slots])
+    with auto-reset, on the board limits that select this <players, slots, parity> instantiation (tests/_harness.py)."""
     B = 24
-    players = {2: [2], 4: [3, 4], 8: [5, 8, 6]}[maxp]
-    small = (max(3, mw - 3), max(3, mh - 2))                    # a ragged batch: some boards smaller than the limit
-    dims = [(mw, mh) if i % 3 else small for i in range(B)]
-    # the variant follows the handle's player limit; a small board takes as many generals as the generator can space out
-    sizes = [d + (min(players[i % len(players)], max(2, d[0] * d[1] // 30)),) for i, d in enumerate(dims)]
+    mw, mh, sizes = H.variant_batch(maxp, slots, parity, B)
     army, owner, typ, w, h, p = H.gen_boards(900 + slots, sizes, mw, mh)
     eng = g.VecEngine(B, mw, mh, maxp, fog_of_war=True, auto_reset=True)
     ora = O.OracleBatch(B, mw, mh, maxp, fog=True)
