@@ -306,3 +306,50 @@ def test_device_stream_deltas_equal_create_stream_update(fog):
     assert seen[1] > 1000 and seen[2] > 50
     eng.close()
     many.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxp", [2, 4, 8])
+@pytest.mark.parametrize("slots,parity", sorted(__import__("_harness").VARIANT_DIMS), ids=__import__("_harness").VARIANT_IDS)
+def test_device_stream_deltas_on_every_kernel_variant(maxp, slots, parity):
+    """The same comparison on the board limits that select each compiled <players, slots, parity> instantiation of
+    stream_delta_kernel: a few turns around the growth turn (deltas, then full states), first and last viewer."""
+    import generalsreinforcementlearning_amd as g
+    import _harness as H
+    B = 6
+    mw, mh, per = H.variant_batch(maxp, slots, parity, B)
+    army, owner, typ, ws, hs, ps = H.gen_boards(300 + slots, per, mw, mh)
+    # player 0 holds every second plain tile: the growth turn then touches more than a fifth of the board (a full state)
+    t = np.arange(mw * mh)[None, :]
+    held = (typ == 0) & (owner < 0) & (t % 2 == 0) & (t < (ws * hs)[:, None])
+    owner[held], army[held] = 0, 2
+    eng = g.VecEngine(B, mw, mh, maxp, fog_of_war=True)
+    eng.reset(army, owner, typ, ws, hs, ps)
+    eng.write_state({"turn": np.full(B, 21, np.int32)})
+    seen = {1: 0, 2: 0}
+    for k in range(6):
+        eng.step(eng.agent_actions(9, 10))
+        st = eng.game_state(fields=wire.STATE_FIELDS)
+        for viewer in (0, maxp - 1):
+            kind, count, upd = eng.stream_deltas(viewer)
+            fk, foff, fupd = eng.stream_deltas_packed(viewer, full_tiles=True)
+            assert np.array_equal(fk, kind)
+            vis, fg = eng.compute_player_visibility(viewer)
+            for e in range(B):
+                w, h, P = per[e]
+                if viewer >= P:
+                    continue
+                want = wire.stream_update(st, vis, fg, np.zeros(w * h * 4, bool), e, viewer)
+                got = wire.stream_update_from_delta(st, kind, count, upd, e, viewer)
+                mine = fupd[foff[e]: foff[e + 1]]
+                seen[int(kind[e])] += 1
+                if want.WhichOneof("update") == "full_state":
+                    assert kind[e] == 2 and got is None and count[e] == 0 and len(mine) == w * h, (k, e, viewer)
+                    assert wire.full_state_from_tiles(st, mine, np.zeros(w * h * 4, bool), e, viewer) == want.full_state, (k, e, viewer)
+                else:
+                    assert kind[e] == 1 and got is not None and np.array_equal(mine, upd[e, : count[e]]), (k, e, viewer)
+                    want.ClearField("timestamp")
+                    got.ClearField("timestamp")
+                    assert got == want, (k, e, viewer)
+    assert seen[1] > 0 and seen[2] > 0
+    eng.close()
