@@ -220,7 +220,7 @@ class _DeviceCollector:
     """The device-side state of a pool whose env, policy and buffer all live on the GPU, and the one call per vector step
     that advances it (gvec_pool_collect)."""
 
-    def __init__(self, env, buffer, max_steps_per_episode, result_capacity):
+    def __init__(self, env, buffer, max_steps_per_episode, result_capacity, prior=None):
         import ctypes
         import torch
         from ._lib import CollectArgs, check
@@ -237,9 +237,14 @@ class _DeviceCollector:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         self.episode_reward, self.episode_length = z(n, torch.float64), z(n, torch.int64)
         self.result_capacity = int(result_capacity)
-        self.result_reward, self.result_length, self.result_worker = (z(self.result_capacity, torch.float64), z(self.result_capacity, torch.int32),
-                                                                      z(self.result_capacity, torch.int32))
-        self.counters = z(4, torch.int64)          # episodes, results held, results dropped, 0
+        if prior is not None and prior.result_capacity == self.result_capacity and prior.counters.device == dev:
+            # the env was re-created (a failed step, a restart): episodes counted and results not yet read stay
+            self.result_reward, self.result_length, self.result_worker, self.counters = (prior.result_reward, prior.result_length,
+                                                                                         prior.result_worker, prior.counters)
+        else:
+            self.result_reward, self.result_length, self.result_worker = (z(self.result_capacity, torch.float64), z(self.result_capacity, torch.int32),
+                                                                          z(self.result_capacity, torch.int32))
+            self.counters = z(4, torch.int64)          # episodes, results held, results dropped, 0
         self.scratch = z((int(self.L.gvec_pool_collect_scratch_bytes(n)) + 7) // 8, torch.int64)
         a = self.args = CollectArgs()
         a.num_envs, a.obs_floats, a.max_steps_per_episode = n, int(np.prod(env.single_observation_shape)), int(max_steps_per_episode)
@@ -379,7 +384,7 @@ class ParallelVecEnvPool:
             if not getattr(self._env, "device_outputs", False) or not self.batched_actions:
                 raise ValueError("a DeviceReplayBuffer needs a vector env with device_outputs=True and batched_actions=True")
             if self._dc is None or self._dc.env is not self._env:
-                self._dc = _DeviceCollector(self._env, self.replay_buffer, self.max_steps_per_episode, self.result_capacity)
+                self._dc = _DeviceCollector(self._env, self.replay_buffer, self.max_steps_per_episode, self.result_capacity, prior=self._dc)
                 import torch
                 self._generator = torch.Generator(device=self._env._dev)
                 self._generator.manual_seed(self.seed)

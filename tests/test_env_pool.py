@@ -369,6 +369,14 @@ def test_device_pool_thread_runs_and_stops():
     assert pool.alive_workers == 0 and pool.total_episodes == len(seen) >= 4 * B
     assert pool.total_env_steps == buf.total_pushed == sum(l for _, l, _ in seen) + int(pool._dc.episode_length.sum())
     assert {w for _, _, w in seen} == set(range(B)) and max(l for _, l, _ in seen) <= 25
+    # a restart opens a new env; what was counted stays counted (like the host form)
+    before, pushed = pool.total_episodes, buf.total_pushed
+    pool.start()
+    t0 = time.time()
+    while pool.total_episodes < before + B and time.time() - t0 < 60:
+        time.sleep(0.02)
+    pool.stop(join_timeout=10.0)
+    assert pool.total_episodes >= before + B and buf.total_pushed > pushed
 
 
 def test_push_batch_is_k_pushes():
