@@ -193,6 +193,74 @@ def expand_records_device(records, layout, stream=None):
     return ex.compact(ex.expand(records, stream))
 
 
+class RecordReplayRing:
+    """A replay memory of COMPACT experience records in HBM: what `ExperienceDataset` (python/experience_stream_client.py:
+    326-378: fill a buffer from the stream, draw random training batches) is to a learner, without the experiences ever
+    being expanded until they are drawn.  A 20x20 4-player record is 3.7 KB and holds the transition of every player that
+    acted; expanded it is 4 x 30 KB of tensors - so 288 GB hold ~70 million transitions' records where they would hold
+    2.5 million expanded ones.  `append_step` has the engine write the records of a step straight into the ring (no staging
+    copy); `sample(k)` draws k records uniformly without replacement, gathers them (k x 3.7 KB) and expands them on the GPU
+    (gvec_expand_experience_records, HBM speed) into decode_records' batch dict - one entry per player that acted, so a draw
+    of k records yields between k and k * players experiences.  Oldest records are overwritten (ring)."""
+
+    def __init__(self, engine, capacity_records, seed=0):
+        import torch
+        self._t, self.engine = torch, engine
+        self.layout = engine.experience_record_layout()
+        self.record_bytes = engine.experience_record_bytes()
+        self.capacity = int(capacity_records)
+        if self.capacity <= 0:
+            raise ValueError(f"capacity must be positive, got {capacity_records}")
+        self.device = torch.device("cuda", engine.device)
+        self.ring = torch.zeros((self.capacity, self.record_bytes), dtype=torch.uint8, device=self.device)
+        self.cursor = self.size = self.total_appended = 0
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(seed))
+        self._expander = None
+
+    def append_step(self, actions=None, env_begin=0, n=None, env_id_base=0):
+        """The records of envs [env_begin, env_begin + n) for the step just played (gvec_experience_begin[_range] before it),
+        written by the engine into the ring at the cursor - in two pieces when the run wraps."""
+        n = self.engine.B - env_begin if n is None else int(n)
+        if n > self.capacity:
+            raise ValueError(f"{n} records per step do not fit a ring of {self.capacity}")
+        first = min(n, self.capacity - self.cursor)
+        self.engine.experience_records(self.ring[self.cursor].data_ptr(), actions, env_begin, first, env_id_base)
+        if first < n:
+            self.engine.experience_records(self.ring[0].data_ptr(), actions, env_begin + first, n - first, env_id_base)
+        self.cursor = (self.cursor + n) % self.capacity
+        self.size = min(self.size + n, self.capacity)
+        self.total_appended += n
+
+    def __len__(self):
+        return self.size
+
+    def sample_indices(self, k):
+        if k > self.size or k < 0:
+            raise ValueError("Sample larger than population or is negative")
+        t = self._t
+        if self.size <= (1 << 16) or 4 * k >= self.size:
+            return t.randperm(self.size, device=self.device, generator=self._gen)[:k]
+        got = t.empty(0, dtype=t.int64, device=self.device)
+        while got.numel() < k:                                   # big ring, small draw: draw, drop repeats, top up
+            both = t.cat([got, t.randint(self.size, (2 * (k - got.numel()) + 16,), device=self.device, generator=self._gen)])
+            uniq, inverse = t.unique(both, return_inverse=True)
+            first = t.full((uniq.numel(),), both.numel(), dtype=t.int64, device=self.device).scatter_reduce_(
+                0, inverse, t.arange(both.numel(), device=self.device), reduce="amin")
+            got = both[first.sort().values]
+        return got[:k]
+
+    def sample(self, k, indices=None):
+        """-> decode_records' batch dict as CUDA tensors (state / next_state [m, 9 * stride] with an experience's own
+        [9, H, W] at the start of its row, action_mask [m, 4 * stride], env, player_id, turn, action, reward, done, width,
+        height) for the m experiences the k drawn records hold.  The tensors are the expander's buffers: valid until the next
+        sample()."""
+        idx = self.sample_indices(k) if indices is None else indices
+        if self._expander is None or self._expander.max_records < len(idx):
+            self._expander = RecordExpander(self.layout, max(len(idx), 1), self.device)
+        return self._expander.compact(self._expander.expand(self.ring[idx]))
+
+
 class ExperienceBatcher:
     """BatchProcessor (internal/grpc/gameserver/batch_processor.go:12-166) as StreamAggregator configures it
     (stream_aggregator.go:64-69: 32 experiences or 100 ms, whichever comes first): add() returns the batches that

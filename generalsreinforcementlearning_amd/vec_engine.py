@@ -83,6 +83,7 @@ class VecEngine:
         else:
             check(self.L.gvec_create(C.byref(cfg), C.byref(self.h)), "gvec_create")
         self.B, self.max_w, self.max_h, self.max_p = num_envs, width, height, players
+        self.device = int(device)          # the device of a plain handle (a sharded one: see `devices`)
         self.stride = self.L.gvec_tile_stride(self.h)
         self.mask_bytes = self.L.gvec_mask_bytes(self.h)
         if stream is not None:

@@ -417,3 +417,51 @@ def test_experience_channel_on_every_kernel_variant(g, maxp, slots, parity):
                     assert np.array_equal(a[: 9 * hw].view(np.uint32), np.asarray(b).reshape(-1).view(np.uint32)) and not a[9 * hw:].any(), (ctx, k, i)
                 assert np.array_equal(xm[i][: 4 * hw], dec["action_mask"][i]) and not xm[i][4 * hw:].any()
     H.assert_states_equal(eng.game_state(), ora.read_state(), ctx)
+
+
+def test_record_replay_ring_holds_what_the_engine_wrote_and_expands_what_it_draws(g):
+    """RecordReplayRing: the ring's rows are the records gvec_experience_records writes for each step (wrapping included),
+    and a draw expands to exactly what decode_records makes of the drawn rows."""
+    import torch
+    from generalsreinforcementlearning_amd.experience import RecordReplayRing, decode_records
+    B, n_rec, steps = 48, 20, 9
+    sizes = [[(10, 10, 2), (12, 9, 3), (8, 8, 2)][i % 3] for i in range(B)]
+    army, owner, typ, w, h, p = H.gen_boards(61, sizes, 12, 10)
+    eng = g.VecEngine(B, 12, 10, 3, auto_reset=True)
+    eng.reset(army, owner, typ, w, h, p)
+    eng.build_board_pool(7, 2)
+    eng.record_agent_actions(True)
+    lay = eng.experience_record_layout()
+    ring = RecordReplayRing(eng, capacity_records=70, seed=3)          # 9 steps x 20 records: wraps twice
+    slab = torch.zeros(n_rec * lay["record_dw"], dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ring.sample(1)
+    want_rows = []
+    for k in range(steps):
+        eng.experience_begin_range(4, n_rec)
+        eng.rollout(1, 900 + k, 5, fused=False)
+        ring.append_step(None, 4, n_rec, env_id_base=100)
+        eng.experience_records(slab.data_ptr(), None, 4, n_rec, 100)
+        eng.synchronize()
+        want_rows.append(slab.cpu().numpy().view(np.uint8).reshape(n_rec, -1).copy())
+    allrows = np.concatenate(want_rows)
+    assert ring.total_appended == steps * n_rec and len(ring) == 70 and ring.cursor == (steps * n_rec) % 70
+    held = ring.ring.cpu().numpy()
+    for j in range(steps * n_rec - 70, steps * n_rec):                  # the last 70 records, where the ring put them
+        assert np.array_equal(held[j % 70], allrows[j]), j
+    idx = ring.sample_indices(32)
+    assert idx.unique().numel() == 32 and int(idx.max()) < 70
+    got = ring.sample(32, indices=idx)
+    dec = decode_records(held[idx.cpu().numpy()].view(np.uint32), lay)
+    assert len(got["env"]) == len(dec["env"]) >= 32
+    for f in ("env", "player_id", "turn", "action", "done", "width", "height"):
+        assert np.array_equal(got[f].cpu().numpy(), np.asarray(dec[f])), f
+    assert np.array_equal(got["reward"].cpu().numpy().view(np.uint32), dec["reward"].view(np.uint32))
+    xs, xn, xm = got["state"].cpu().numpy(), got["next_state"].cpu().numpy(), got["action_mask"].cpu().numpy()
+    for i in range(len(dec["env"])):
+        hw = int(dec["width"][i]) * int(dec["height"][i])
+        assert np.array_equal(xs[i][: 9 * hw].view(np.uint32), np.asarray(dec["state"][i]).reshape(-1).view(np.uint32))
+        assert np.array_equal(xn[i][: 9 * hw].view(np.uint32), np.asarray(dec["next_state"][i]).reshape(-1).view(np.uint32))
+        assert np.array_equal(xm[i][: 4 * hw], dec["action_mask"][i])
+    with pytest.raises(ValueError):
+        ring.append_step(None, 0, 71)
