@@ -424,10 +424,12 @@ class ParallelVecEnvPool:
         idx = np.flatnonzero(live)
         if len(idx):
             if hasattr(self.replay_buffer, "push_batch"):
-                if len(idx) == self.num_envs:        # the usual step: no worker is re-dealing, nothing to pick out (push_batch copies)
+                if len(idx) == self.num_envs and isinstance(self.replay_buffer, ReplayBuffer):
+                    # the usual step: no worker is re-dealing, nothing to pick out - and this package's ring copies what it is
+                    # given, so the env's own (soon reused) arrays can be handed over as they are
                     self.replay_buffer.push_batch(state, actions, reward, next_state, done)
                 else:
-                    self.replay_buffer.push_batch(state[idx], actions[idx], reward[idx], next_state[idx], done[idx])
+                    self.replay_buffer.push_batch(np.array(state[idx]), actions[idx], reward[idx], np.array(next_state[idx]), done[idx])
             else:
                 for w in idx:
                     self.replay_buffer.push(np.array(state[w]), int(actions[w]), float(reward[w]), np.array(next_state[w]), bool(done[w]))
