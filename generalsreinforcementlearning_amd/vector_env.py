@@ -19,9 +19,10 @@ server.go:526-553 (army_count = Player.ArmyCount, tile_count = len(OwnedTiles), 
 There is one execution path: the gym kernels behind the C ABI.  (The readable numpy restatement they
 are tested against lives in tests/_gym_reference.py; it was a third mode of this class up to round 2.)
 
-Deliberate differences (documented in DESIGN.md): opponents are the on-device random agent
+Deliberate differences (documented in DESIGN.md): opponents are by default the on-device random agent
 (uniform over legal moves, 30 % half moves, 10 % no-op) instead of Python's `random.choice` over
-full moves; finished / truncated envs are re-dealt on their next step ("next-step" autoreset)
+full moves - or whatever the caller supplies per step (`step(actions, other_actions=...)`: an opponent
+policy, self-play; GeneralsEnv's `opponent_agent`); finished / truncated envs are re-dealt on their next step ("next-step" autoreset)
 because a vector env cannot wait for a per-env reset() call.
 """
 import numpy as np
@@ -81,6 +82,7 @@ class GeneralsVecEnv:
                         for _ in range(3)]
         self._step_no = 0
         self._arg_cache = {}
+        self._acts, self.last_actions = None, None
         if not self.device_outputs:   # pinned landing buffers for the default (numpy) mode
             pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
             self._h_obs = [pin((num_envs, 9, board_height, board_width), torch.float32) for _ in range(2)]
@@ -140,6 +142,42 @@ class GeneralsVecEnv:
         self.valid_actions_mask = info["valid_actions_mask"]
         return obs, out["reward"], out["terminated"], out["truncated"], dict(info)
 
+    def _step_composed(self, actions, others):
+        """The same step with the OTHER players' moves supplied by the caller - an opponent policy, self-play - instead of
+        drawn by the on-device agent: `others` is [num_envs][max_players] gvec_action (numpy ACTION_DTYPE, or a CUDA uint8
+        tensor [num_envs, max_players, 8]); the learner's slot is ignored.  Four launches - gvec_gym_actions (the learner's
+        action decoded into its slot, a refused one makes the env sit the call out) -> gvec_step -> gvec_gym_finish_step -
+        which together equal gvec_gym_step output for output when `others` are the agent's moves
+        (tests/test_vector_env.py::test_gym_step_equals_the_four_call_composition)."""
+        t, e, B, P = self._t, self.engine, self.num_envs, self.max_players
+        if not (isinstance(actions, t.Tensor) and actions.is_cuda and actions.dtype == t.int64 and actions.is_contiguous() and actions.numel() == B):
+            if isinstance(actions, np.ndarray):
+                actions = t.from_numpy(np.ascontiguousarray(actions, np.int64))
+            actions = t.as_tensor(actions, dtype=t.int64).to(self._dev).reshape(B).contiguous()
+        if self._acts is None:
+            self._acts = t.zeros((B, P, 8), dtype=t.uint8, device=self._dev)
+        if isinstance(others, np.ndarray):
+            from .vec_engine import ACTION_DTYPE
+            others = t.from_numpy(np.ascontiguousarray(others, ACTION_DTYPE).reshape(B, P).view(np.uint8).reshape(B, P, 8))
+        self._acts.copy_(others.reshape(B, P, 8))
+        self.last_actions = actions
+        k = self._step_no
+        self._step_no += 1
+        prev_mask = self._d_mask[self._obs_flip]                       # the mask of the observation the learner acted on
+        self._obs_flip ^= 1
+        _, obs, out, info = self._step_args(k, self._obs_flip)
+        cur, mask = self._d_step[k % 3], self._d_mask[self._obs_flip]
+        L, pl = e.L, self.player_id
+        check(L.gvec_gym_actions(e.h, pl, actions.data_ptr(), prev_mask.data_ptr(), cur["needs_reset"].data_ptr(), self._acts.data_ptr(),
+                                 out["played"].data_ptr(), out["invalid"].data_ptr(), out["error"].data_ptr()), "gvec_gym_actions")
+        e.step_device(self._acts.data_ptr())
+        check(L.gvec_gym_finish_step(e.h, pl, self._d_turn.data_ptr(), self.max_turns, cur["needs_reset"].data_ptr(), out["played"].data_ptr(),
+                                     obs.data_ptr(), mask.data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(),
+                                     out["truncated"].data_ptr(), out["winner"].data_ptr(), out["needs_reset"].data_ptr(),
+                                     out["turn"].data_ptr()), "gvec_gym_finish_step")
+        self.valid_actions_mask = info["valid_actions_mask"]
+        return obs, out["reward"], out["terminated"], out["truncated"], dict(info)
+
     def _to_numpy(self, obs, info):
         """The device path's outputs as numpy arrays (default mode): observation and mask land in pinned buffers that
         alternate, so the arrays returned by step k stay intact until step k + 2."""
@@ -161,10 +199,13 @@ class GeneralsVecEnv:
         obs, info = self._reset_device()
         return (obs, info) if self.device_outputs else self._to_numpy(obs, info)
 
-    def step(self, actions):
+    def step(self, actions, other_actions=None):
+        """other_actions: None = the other players are the on-device random agent (ONE launch); else their moves for this
+        step ([num_envs][max_players] gvec_action, see _step_composed)."""
+        run = self._step_device if other_actions is None else (lambda a: self._step_composed(a, other_actions))
         if self.device_outputs:
-            return self._step_device(actions)
-        obs, reward, terminated, truncated, info = self._step_device(np.asarray(actions, np.int64))
+            return run(actions)
+        obs, reward, terminated, truncated, info = run(np.asarray(actions, np.int64))
         obs, info = self._to_numpy(obs, info)
         return obs, reward.cpu().numpy(), terminated.cpu().numpy(), truncated.cpu().numpy(), info
 
@@ -224,15 +265,16 @@ class GeneralsEnv:
     the game does not advance; otherwise info carries turn / valid_actions_mask / game_status / winner), `render`, `close` -
     served by a ONE-board GeneralsVecEnv instead of a gRPC server (`server_address` is kept as an attribute only).  One board
     per launch wastes the GPU: use GeneralsVecEnv / ParallelVecEnvPool for throughput; this class is for code that wants the
-    reference's object.  Opponent: the on-device random agent (the reference's default is a random opponent too, :443-497;
-    a custom `opponent_agent` needs the proto GameState and is not supported)."""
+    reference's object.  Opponent: the on-device random agent (the reference's default is a random opponent too, :443-497),
+    or `opponent_agent` - any object with the reference's `select_action(game_state_proto) -> Action proto | None`
+    (:244-255): it is handed the learner's proto GameState (wire.game_state: the reference passes `self.current_state`), its
+    move is played for player 1 (GeneralsVecEnv.step(..., other_actions=...); the remaining seats of a game with more than
+    two players then do not move).  `self_play` is an attribute the reference stores and never reads; so here."""
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
 
     def __init__(self, server_address="localhost:50051", board_width=15, board_height=15, max_players=2, fog_of_war=True,
                  render_mode=None, self_play=False, opponent_agent=None, max_turns=500, turn_time_ms=500,
                  collect_experiences=False, device=0, seed=0):
-        if opponent_agent is not None or self_play:
-            raise NotImplementedError("opponent_agent / self_play act on the proto GameState of a gRPC server; opponents here are the on-device random agent")
         self.server_address, self.board_width, self.board_height = server_address, board_width, board_height
         self.board_size = board_width * board_height
         self.max_players, self.fog_of_war, self.render_mode = max_players, fog_of_war, render_mode
@@ -260,8 +302,29 @@ class GeneralsEnv:
         return self._obs, {"game_id": self.game_id, "player_id": self.player_id, "valid_actions_mask": self.valid_actions_mask,
                            "turn": self.turn_count}
 
+    def _proto_state(self):
+        """`self.current_state` of the reference (:256-262): the proto GameState the server sends for the learner's token."""
+        from . import wire
+        e = self._vec.engine
+        st = e.game_state(fields=wire.STATE_FIELDS)
+        vis, fog = e.compute_player_visibility(self.player_id)
+        return wire.game_state(st, vis, fog, e.get_legal_action_mask(0, self.player_id), 0, self.player_id, game_id=self.game_id or "",
+                               names=["RL_Agent", "Opponent"] + [f"player{p}" for p in range(2, self.max_players)])
+
+    def _opponent_moves(self):
+        """generals_env.py:244-255: `opponent_agent.select_action(self.current_state)` - the reference hands the opponent the
+        LEARNER's state - returns a proto Action (or None = no move), submitted with the opponent's token (player 1)."""
+        from .vec_engine import ACTION_DTYPE
+        others = np.zeros((1, self.max_players), ACTION_DTYPE)
+        act = self.opponent_agent.select_action(self._proto_state())
+        if act:
+            src = getattr(act, "from")
+            others[0, 1] = (src.x, src.y, act.to.x, act.to.y, 1 | (2 if getattr(act, "half", False) else 0), (0, 0, 0))   # GVEC_ACT_VALID | _HALF
+        return others
+
     def step(self, action):
-        obs, reward, terminated, truncated, info = self._vec.step(np.array([int(action)], np.int64))
+        others = self._opponent_moves() if self.opponent_agent is not None else None
+        obs, reward, terminated, truncated, info = self._vec.step(np.array([int(action)], np.int64), other_actions=others)
         self._obs = obs[0].copy()
         if info["invalid_action"][0]:                                           # :226-231
             return self._obs, -0.1, False, False, {"invalid_action": True}

@@ -526,5 +526,93 @@ def test_single_env_facade_has_the_reference_env_s_shape():
     assert ended and steps > 30
     env.render()
     env.close()
-    with pytest.raises(NotImplementedError):
-        GeneralsEnv(opponent_agent=object())
+
+
+@pytest.mark.gpu
+def test_step_with_supplied_opponent_moves_equals_the_one_launch_step():
+    """GeneralsVecEnv.step(actions, other_actions=...) - the other players' moves supplied by the caller - with exactly the
+    moves the on-device agent would have drawn equals the one-launch step, output for output and state for state."""
+    from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
+    B = 96
+    mk = lambda: GeneralsVecEnv(B, board_width=9, board_height=8, max_players=3, max_turns=20, seed=4, board_pool=16)
+    one, two = mk(), mk()
+    (oa, ia), (ob, ib) = one.reset(), two.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(2)
+    for k in range(60):
+        m = ia["valid_actions_mask"]
+        acts = np.array([rng.choice(np.flatnonzero(r)) if r.any() else 0 for r in m], np.int64)
+        if k % 5 == 2:
+            acts[:6] = [int(np.flatnonzero(~r)[0]) for r in m[:6]]                       # refused: those envs sit the step out
+        others = two.engine.agent_actions(4 + 1000 * k + 1, 0)                            # what step k's launch draws (vector_env.py: seed formula)
+        a = one.step(acts)
+        b = two.step(acts, other_actions=others)
+        for x, y, name in zip(a[:4], b[:4], ("obs", "reward", "terminated", "truncated")):
+            assert np.array_equal(x, y), (k, name)
+        ia, ib = a[4], b[4]
+        assert set(ia) == set(ib)
+        for f in ia:
+            assert np.array_equal(ia[f], ib[f]), (k, f)
+    H.assert_states_equal(one.engine.game_state(), two.engine.game_state(), "supplied opponents")
+    one.close(); two.close()
+
+
+@pytest.mark.gpu
+def test_single_env_facade_plays_an_opponent_agent():
+    """GeneralsEnv(opponent_agent=...): the agent is handed the learner's proto GameState (as the reference does) and its
+    Action is played for player 1 - checked against the oracle engine stepped with the same two moves."""
+    import types
+    import _oracle as O
+    from generalsreinforcementlearning_amd import wire
+    from generalsreinforcementlearning_amd.vec_engine import ACTION_DTYPE
+    from generalsreinforcementlearning_amd.vector_env import GeneralsEnv
+    W, Hh = 7, 6
+    ora = O.OracleBatch(1, W, Hh, 2, fog=True)
+    rng = np.random.default_rng(9)
+    seen = {"states": 0, "moves": 0, "none": 0}
+
+    class Opponent:                                        # picks among player 1's TRUE legal moves (it knows the oracle), or passes
+        def select_action(self, state):
+            assert type(state).__name__ == "GameState" and state.board.width == W and len(state.board.tiles) == W * Hh
+            assert state.turn == int(ora.read_state()["turn"][0]) and [p.name for p in state.players] == ["RL_Agent", "Opponent"]
+            seen["states"] += 1
+            legal = np.flatnonzero(ora.engine(0).legal_mask(1))
+            if len(legal) == 0 or rng.random() < 0.2:
+                seen["none"] += 1
+                self.last = None
+                return None
+            m = int(rng.choice(legal))
+            t, d = m // 4, m % 4
+            fx, fy = t % W, t // W
+            dx, dy = [(0, -1), (1, 0), (0, 1), (-1, 0)][d]                   # Engine.GetLegalActionMask: up, right, down, left
+            seen["moves"] += 1
+            self.last = (fx, fy, fx + dx, fy + dy, bool(rng.random() < 0.3))
+            NS = types.SimpleNamespace
+            return NS(**{"from": NS(x=fx, y=fy), "to": NS(x=fx + dx, y=fy + dy), "half": self.last[4]})
+
+    opp = Opponent()
+    env = GeneralsEnv(board_width=W, board_height=Hh, max_players=2, fog_of_war=True, max_turns=60, opponent_agent=opp, seed=3)
+    obs, info = env.reset()
+    st = env._vec.engine.game_state()
+    ora.reset(st["army"], st["owner"], st["type"], st["width"], st["height"], st["players"])
+    H.assert_states_equal(env._vec.engine.game_state(), ora.read_state(), "after reset")
+    for k in range(50):
+        mask = info["valid_actions_mask"]
+        full = np.flatnonzero(mask.reshape(-1, 5)[:, :4].reshape(-1))                      # full moves only: tile * 4 + d
+        if len(full) == 0:
+            break
+        m = int(rng.choice(full))
+        t, d = m // 4, m % 4
+        fx, fy = t % W, t // W
+        dx, dy = [(0, -1), (1, 0), (0, 1), (-1, 0)][d]
+        obs, r, term, trunc, info = env.step(t * 5 + d)
+        acts = np.zeros((1, 2), ACTION_DTYPE)
+        acts[0, 0] = (fx, fy, fx + dx, fy + dy, 1, (0, 0, 0))
+        if opp.last is not None:
+            acts[0, 1] = opp.last[:4] + (1 | (2 if opp.last[4] else 0), (0, 0, 0))
+        ora.step(acts)
+        H.assert_states_equal(env._vec.engine.game_state(), ora.read_state(), f"turn {k}")
+        if term or trunc:
+            break
+    assert seen["states"] >= 10 and seen["moves"] > 5 and seen["none"] > 0
+    env.close()
