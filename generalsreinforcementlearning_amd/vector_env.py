@@ -339,24 +339,29 @@ class GeneralsEnv:
             "winner": int(info["winner"][0]) if term else None}
 
     def render(self):
-        if self.render_mode == "human" and self._obs is not None:               # :563-597, from the observation channels
-            o = self._obs
-            print(f"\nTurn {self.turn_count}")
-            for y in range(self.board_height):
-                row = "|"
-                for x in range(self.board_width):
-                    if not o[0, y, x]:
-                        cell = " ? "
-                    elif o[4, y, x]:
-                        cell = "###"
-                    elif o[1, y, x] == 0.5:
-                        cell = f" {int(round(float(np.exp(o[2, y, x] * 10.0)) - 1)):2}"
-                    elif o[1, y, x] == 1.0:
-                        cell = f"-{int(round(float(np.exp(o[2, y, x] * 10.0)) - 1)):2}"
-                    else:
-                        cell = " . "
-                    row += cell + "|"
-                print(row)
+        """:563-597: the learner's view as text ("human" mode only), from the proto state like the reference's."""
+        if self.render_mode != "human" or self._obs is None:
+            return
+        tiles = self._proto_state().board.tiles
+        bar = "=" * (self.board_width * 4 + 1)
+        print(f"\nTurn {self.turn_count}")
+        print(bar)
+        for y in range(self.board_height):
+            cells = []
+            for x in range(self.board_width):
+                tile = tiles[y * self.board_width + x]
+                if not tile.visible:
+                    cells.append(" ? ")
+                elif tile.type == 4:                                   # TILE_TYPE_MOUNTAIN (common.proto)
+                    cells.append("###")
+                elif tile.owner_id == self.player_id:
+                    cells.append(f" {tile.army_count:2}")
+                elif tile.owner_id >= 0:
+                    cells.append(f"-{tile.army_count:2}")
+                else:
+                    cells.append(" . ")
+            print("|" + "|".join(cells) + "|")
+        print(bar)
 
     def close(self):
         self._vec.close()

@@ -558,7 +558,7 @@ def test_step_with_supplied_opponent_moves_equals_the_one_launch_step():
 
 
 @pytest.mark.gpu
-def test_single_env_facade_plays_an_opponent_agent():
+def test_single_env_facade_plays_an_opponent_agent(capsys):
     """GeneralsEnv(opponent_agent=...): the agent is handed the learner's proto GameState (as the reference does) and its
     Action is played for player 1 - checked against the oracle engine stepped with the same two moves."""
     import types
@@ -615,4 +615,9 @@ def test_single_env_facade_plays_an_opponent_agent():
         if term or trunc:
             break
     assert seen["states"] >= 10 and seen["moves"] > 5 and seen["none"] > 0
+    env.render_mode = "human"
+    capsys.readouterr()
+    env.render()                                            # the learner's view as text, like _print_board (:568-597)
+    text = capsys.readouterr().out.splitlines()
+    assert text[1].startswith("Turn ") and text[2] == "=" * (W * 4 + 1) and len(text) == Hh + 4 and all(len(r) == W * 4 + 1 for r in text[3:3 + Hh])
     env.close()
