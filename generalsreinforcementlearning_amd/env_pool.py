@@ -366,7 +366,7 @@ class ParallelVecEnvPool:
         while True:
             tries += 1
             try:
-                env = self.env_factory(self.num_envs)
+                env = self._open_env()
             except Exception as e:  # noqa: BLE001
                 logger.warning("opening the vector environment failed (%d of %d): %s", tries, self.max_env_retries, e)
                 if tries >= self.max_env_retries:
@@ -375,6 +375,9 @@ class ParallelVecEnvPool:
             else:
                 logger.info("vector environment open")
                 return env
+
+    def _open_env(self):
+        return self.env_factory(self.num_envs)
 
     def _begin(self):
         """Every worker's first `env.reset()` (vector_env.py:166-167)."""

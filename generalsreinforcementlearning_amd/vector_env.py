@@ -279,7 +279,7 @@ class GeneralsEnv:
         self.board_size = board_width * board_height
         self.max_players, self.fog_of_war, self.render_mode = max_players, fog_of_war, render_mode
         self.self_play, self.opponent_agent, self.max_turns = self_play, opponent_agent, max_turns
-        self.turn_time_ms, self.collect_experiences = turn_time_ms, collect_experiences
+        self.turn_time_ms, self.collect_experiences, self.device = turn_time_ms, collect_experiences, device
         self._vec = GeneralsVecEnv(1, board_width, board_height, max_players, fog_of_war=fog_of_war, max_turns=max_turns, seed=seed,
                                    device=device, board_pool=4)
         self._seed, self._games = seed, 0

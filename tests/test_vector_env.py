@@ -497,9 +497,8 @@ def test_gym_step_equals_the_four_call_composition(w, h, P, fog):
 @pytest.mark.gpu
 def test_single_env_facade_has_the_reference_env_s_shape():
     """GeneralsEnv (the single-env object code written for the reference instantiates): constructor keywords, spaces,
-    reset / step tuples and info keys of generals_env.py:48-289; an episode loop like python/test_gym_env.py's; and the
-    REFERENCE-shaped env_factory(worker_id) of ParallelEnvPool driving it unchanged through this package's pool in its
-    per-worker form."""
+    reset / step tuples and info keys of generals_env.py:48-289; an episode loop like python/test_gym_env.py's.  (The
+    reference-shaped env_factory(worker_id) driving a pool of them: tests/test_env_pool.py, generals_gym.ParallelEnvPool.)"""
     from generalsreinforcementlearning_amd.vector_env import GeneralsEnv
     env = GeneralsEnv(server_address="localhost:50051", board_width=6, board_height=5, max_players=2, fog_of_war=False, max_turns=30)
     assert env.observation_space.shape == (9, 5, 6) and env.observation_space.dtype == np.float32 and env.action_space.n == 150
