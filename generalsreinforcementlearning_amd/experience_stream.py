@@ -248,3 +248,46 @@ def engine_experience_source(engine, records_per_step, seed=0, max_steps=None, g
             yield last
 
     return factory
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The reference's constructor, `ExperienceStreamClient(config)` (rl_training_example.py:173): there "the server" is named by
+# config.server_address; here it is a local engine, opened by connect() with the settings below (configure_local_engine
+# before connect() to change them).  generalsreinforcementlearning_amd/experience_stream_client.py re-exports these under
+# the reference's module name.
+# --------------------------------------------------------------------------------------------------------------------
+_LOCAL_ENGINE = {"num_envs": 1024, "width": 20, "height": 20, "players": 2, "fog_of_war": True, "records_per_step": 128, "seed": 0,
+                 "device": 0, "board_pool": 256, "max_steps": None}
+
+
+def configure_local_engine(**settings):
+    """What stands in for the game server behind `ExperienceStreamClient(config)`: num_envs boards of width x height with
+    `players` players played by the on-device agent, the experience records of `records_per_step` of them streamed per turn."""
+    unknown = set(settings) - set(_LOCAL_ENGINE)
+    if unknown:
+        raise TypeError(f"unknown settings {sorted(unknown)}; known: {sorted(_LOCAL_ENGINE)}")
+    _LOCAL_ENGINE.update(settings)
+
+
+class ExperienceStreamClient(VecExperienceStreamClient):
+    def __init__(self, config):
+        self._engine = None
+        super().__init__(config, self._open_local_source)
+
+    def _open_local_source(self, config):
+        import torch
+
+        from .vec_engine import VecEngine
+        s = dict(_LOCAL_ENGINE)
+        dev = torch.device("cuda", s["device"])
+        with torch.cuda.device(dev):
+            eng = VecEngine(s["num_envs"], s["width"], s["height"], s["players"], fog_of_war=s["fog_of_war"], device=s["device"], auto_reset=True,
+                            stream=torch.cuda.current_stream(dev).cuda_stream)
+            eng.reset_generated(s["seed"] * 1000003 + 17)
+            eng.build_board_pool(s["board_pool"], s["seed"] * 7919 + 5)
+            self._engine = eng
+            try:
+                yield from engine_experience_source(eng, min(s["records_per_step"], s["num_envs"]), seed=s["seed"], max_steps=s["max_steps"])(config)
+            finally:
+                self._engine = None
+                eng.close()

@@ -157,3 +157,39 @@ def test_stream_client_over_an_engine_source():
     sel = c2.get_batch(10 ** 6, timeout=0.5)
     assert sel and all(d["game_id"] in ("vec-env3", "vec-env5") and d["player_id"] == 1 for d in sel)
     assert [(d["game_id"], d["turn"]) for d in sel] == [(d["game_id"], d["turn"]) for d in got if d["game_id"] in ("vec-env3", "vec-env5") and d["player_id"] == 1]
+
+
+@pytest.mark.gpu
+def test_reference_shaped_training_loop_on_the_reference_names():
+    """rl_training_example.py:164-240 in outline, with nothing changed but the import: ExperienceStreamClient(config) ->
+    connect -> start_streaming -> ExperienceDataset(client, buffer_size) -> fill_buffer(min_size) -> sample(batch) ->
+    get_stats -> stop_streaming -> disconnect."""
+    from generalsreinforcementlearning_amd.experience_stream_client import (ExperienceConfig, ExperienceDataset, ExperienceStreamClient,
+                                                                            configure_local_engine)
+    configure_local_engine(num_envs=128, width=10, height=10, players=2, records_per_step=32, seed=3, board_pool=32)
+    with pytest.raises(TypeError):
+        configure_local_engine(boards=3)
+    config = ExperienceConfig(server_address="localhost:50051", batch_size=64, follow=True, buffer_size=2000)
+    client = ExperienceStreamClient(config)
+    client.connect()
+    client.start_streaming()
+    try:
+        import time
+        t0 = time.time()
+        while client.get_stats()["total_experiences"] < 500 and time.time() - t0 < 120:   # the engine opens on the stream thread
+            time.sleep(0.05)
+        dataset = ExperienceDataset(client, buffer_size=1000)
+        dataset.fill_buffer(min_size=400)
+        assert len(dataset.buffer) >= 400
+        batch = dataset.sample(32)
+        assert len(batch) == 32
+        e = batch[0]
+        assert set(e) >= {"experience_id", "game_id", "player_id", "turn", "state", "action", "reward", "next_state", "done", "action_mask"}
+        assert e["state"].shape == (9, 10, 10) and e["state"].dtype == np.float32 and e["next_state"].shape == (9, 10, 10)
+        assert e["action_mask"].shape == (400,) and isinstance(e["action"], int) and isinstance(e["reward"], float) and isinstance(e["done"], bool)
+        stats = client.get_stats()
+        assert stats["total_experiences"] >= 400 and stats["total_batches"] >= 400 // 64 and "queue_size" in stats and "dropped_experiences" in stats
+    finally:
+        client.stop_streaming()
+        client.disconnect()
+    assert client._engine is None
