@@ -931,8 +931,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_observe_kernel(GymAr
 // decoded against the valid-action mask of the resident state (recomputed from the planes in registers - the bytes
 // gym_observe wrote are not read back), the opponents' moves come from the on-device agent, the turn is played, and the
 // observation / mask / reward / flags of the NEW state leave while the board is still in registers.
+// (Five waves per SIMD asked for by name: left alone the compiler takes 107-145 VGPRs - four waves, three for the largest
+// boards; told to fit five it needs 81-96 and spills nothing except 24-28 bytes in <8,16>.  65,536 envs: 16x16 0.201 ->
+// 0.184 ms, 20x20 4P 0.290 -> 0.260, 10x10 0.157 -> 0.140, 32x32 8P 0.586 -> 0.556, 15x15 and 25x25 unchanged; six waves
+// (73-80 VGPRs) gain on boards of up to 256 tiles and lose 8-15 % on every larger one.)
 template <int MAXP, int NSLOT, bool ODD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void gym_step_kernel(StepArgs A, GymStepArgs G) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void gym_step_kernel(StepArgs A, GymStepArgs G) {
   constexpr int FD = 2 * NSLOT - (ODD ? 1 : 0);
   constexpr int ROW_DW = (Planes<MAXP>::COUNT * FD + 3) / 4 * 4;
   constexpr int STAGE_DW = (NSLOT * 64 * 5 + 15) / 16 * 4;  // the gym mask's stage (5 bytes a tile) is the larger user of the army shadow
