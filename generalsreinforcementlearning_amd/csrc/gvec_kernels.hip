@@ -781,33 +781,97 @@ template <int NSLOT, typename BT>
 __device__ __forceinline__ void gym_emit(const BT& b, uint32_t seen, uint32_t own_p, uint32_t own_any, uint32_t m0, uint32_t m1, uint32_t m2,
                                          uint32_t m3, uint32_t many, float tc, float* obs, uint8_t* mask, uint8_t* ms, int stride) {
   const int lane = lane_id();
+  const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(obs) >> 2);
+  if (((a0 | (uint32_t)stride) & 3u) != 0u) {
+    // Planes of W*H floats that do not even start on 16-byte boundaries (odd W*H - 15x15: 900 bytes at multiples of 900;
+    // 25x25: 2,500): a store of "tiles 64s .. 64s+63" begins anywhere in a line, and such stores leave at a third of the rate
+    // of aligned ones (65,536 envs: the nine planes of 25x25 took 0.53 ms, those of 32x32 - 1.6x the bytes - 0.21).  So every
+    // store covers an ALIGNED window of 64 floats instead, lane l of window k holding tile 64k - sh + l of its plane (sh: the
+    // plane's dword offset inside its 256-byte line), whose bits come with the same ds_bpermute a slot's would: 25x25 0.77 ->
+    // 0.47 ms, 15x15 0.256 -> 0.232.  (Planes on 16-byte boundaries are better off with the stores below - 10x10 0.140 vs
+    // 0.162 ms this way, 20x20 0.260 vs 0.283 - whose per-slot bits all nine planes share.)
+    auto at = [&](uint32_t plane, int t) { return __builtin_amdgcn_ubfe(bperm((t >> 5) << 2, plane), (uint32_t)(t & 31), 1u) != 0u; };
+    auto emit = [&](int p, auto&& value) {
+      float* base = obs + (size_t)p * (size_t)stride;
+      const int sh = (int)((a0 + (uint32_t)p * (uint32_t)stride) & 63u);
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    const int t = 64 * s + lane;
-    const bool vis = b.gather(seen, s) != 0u, mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u;
-    const bool g = b.gather(b.gen, s) != 0u, c = b.gather(b.city, s) != 0u, mt = b.gather(b.mtn, s) != 0u;
-    const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
-    const int32_t army = vis ? b.army[s] : 0;                                    // hidden and fogged tiles: army 0
-    // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
-    const float la = (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
-    if (t < stride) {
-      const bool in = t < b.N;
-      const size_t n = (size_t)stride;
-      st_stream<GVEC_NT_MASK>(obs + 0 * n + t, (in && vis) ? 1.0f : 0.0f);                                // :312-314
-      st_stream<GVEC_NT_MASK>(obs + 1 * n + t, (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f));   // :316-322 (owner -1 unless visible)
-      st_stream<GVEC_NT_MASK>(obs + 2 * n + t, in ? la : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 3 * n + t, (in && !g && !c && !mt) ? 1.0f : 0.0f);                    // :328-336 one-hot type
-      st_stream<GVEC_NT_MASK>(obs + 4 * n + t, (in && mt) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 5 * n + t, (in && c) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 6 * n + t, (in && g) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(obs + 7 * n + t, tc);                                                       // the whole plane, like obs[7, :, :] = ...
-      st_stream<GVEC_NT_MASK>(obs + 8 * n + t, 0.0f);                                                     // left zero by the reference (:341-343)
-      uint8_t* mk = ms + t * 5;
-      mk[0] = (uint8_t)k0;
-      mk[1] = (uint8_t)k1;
-      mk[2] = (uint8_t)k2;
-      mk[3] = (uint8_t)k3;
-      mk[4] = (uint8_t)k4;
+      for (int k = 0; k <= NSLOT; ++k) {
+        if (64 * k - sh < stride) {                  // wave-uniform
+          const int t = 64 * k - sh + lane;
+          const bool ok = t >= 0 && t < stride;
+          const int tt = ok ? t : 0;
+          const float v = value(k, tt, sh, ok && tt < b.N);
+          if (ok) st_stream<GVEC_NT_MASK>(base + t, v);
+        }
+      }
+    };
+    emit(0, [&](int, int t, int, bool in) { const bool vis = at(seen, t); return (vis && in) ? 1.0f : 0.0f; });          // :312-314
+    emit(1, [&](int, int t, int, bool in) {                                                                          // :316-322 (owner -1 unless visible)
+      const bool vis = at(seen, t), mine = at(own_p, t), owned = at(own_any, t);
+      return (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f);
+    });
+    emit(2, [&](int k, int t, int sh, bool in) {
+      // the army of tile 64k - sh + l sits in slot k (lanes l >= sh) or k - 1 (l < sh), sh lanes further on
+      const int from = ((lane - sh) & 63) << 2;
+      const int32_t cur = (int32_t)bperm(from, (uint32_t)b.army[k < NSLOT ? k : NSLOT - 1]);
+      const int32_t prv = (int32_t)bperm(from, (uint32_t)b.army[k > 0 ? k - 1 : 0]);
+      const bool vis = at(seen, t);
+      const int32_t army = (vis && in) ? ((lane >= sh) ? cur : prv) : 0;         // hidden and fogged tiles: army 0
+      // np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
+      return (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
+    });
+    // (every at() is a ds_bpermute and reads zeros from lanes that sit out: never behind a lane-dependent `&&`)
+    emit(3, [&](int, int t, int, bool in) {                                                                          // :328-336 one-hot type
+      const bool g = at(b.gen, t), c = at(b.city, t), mt = at(b.mtn, t);
+      return (in && !g && !c && !mt) ? 1.0f : 0.0f;
+    });
+    emit(4, [&](int, int t, int, bool in) { const bool mt = at(b.mtn, t); return (in && mt) ? 1.0f : 0.0f; });
+    emit(5, [&](int, int t, int, bool in) { const bool c = at(b.city, t); return (in && c) ? 1.0f : 0.0f; });
+    emit(6, [&](int, int t, int, bool in) { const bool g = at(b.gen, t); return (in && g) ? 1.0f : 0.0f; });
+    emit(7, [&](int, int, int, bool) { return tc; });                                                                // the whole plane, like obs[7, :, :] = ...
+    emit(8, [&](int, int, int, bool) { return 0.0f; });                                                              // left zero by the reference (:341-343)
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
+      if (t < stride) {
+        uint8_t* mk = ms + t * 5;
+        mk[0] = (uint8_t)k0;
+        mk[1] = (uint8_t)k1;
+        mk[2] = (uint8_t)k2;
+        mk[3] = (uint8_t)k3;
+        mk[4] = (uint8_t)k4;
+      }
+    }
+  } else {
+  #pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int t = 64 * s + lane;
+      const bool vis = b.gather(seen, s) != 0u, mine = b.gather(own_p, s) != 0u, owned = b.gather(own_any, s) != 0u;
+      const bool g = b.gather(b.gen, s) != 0u, c = b.gather(b.city, s) != 0u, mt = b.gather(b.mtn, s) != 0u;
+      const uint32_t k0 = b.gather(m0, s), k1 = b.gather(m1, s), k2 = b.gather(m2, s), k3 = b.gather(m3, s), k4 = b.gather(many, s);
+      const int32_t army = vis ? b.army[s] : 0;                                    // hidden and fogged tiles: army 0
+      // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326)
+      const float la = (army > 0) ? (float)(log((double)army + 1.0) / 10.0) : 0.0f;
+      if (t < stride) {
+        const bool in = t < b.N;
+        const size_t n = (size_t)stride;
+        st_stream<GVEC_NT_MASK>(obs + 0 * n + t, (in && vis) ? 1.0f : 0.0f);                                // :312-314
+        st_stream<GVEC_NT_MASK>(obs + 1 * n + t, (in && vis && mine) ? 0.5f : ((in && vis && owned) ? 1.0f : 0.0f));   // :316-322 (owner -1 unless visible)
+        st_stream<GVEC_NT_MASK>(obs + 2 * n + t, in ? la : 0.0f);
+        st_stream<GVEC_NT_MASK>(obs + 3 * n + t, (in && !g && !c && !mt) ? 1.0f : 0.0f);                    // :328-336 one-hot type
+        st_stream<GVEC_NT_MASK>(obs + 4 * n + t, (in && mt) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(obs + 5 * n + t, (in && c) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(obs + 6 * n + t, (in && g) ? 1.0f : 0.0f);
+        st_stream<GVEC_NT_MASK>(obs + 7 * n + t, tc);                                                       // the whole plane, like obs[7, :, :] = ...
+        st_stream<GVEC_NT_MASK>(obs + 8 * n + t, 0.0f);                                                     // left zero by the reference (:341-343)
+        uint8_t* mk = ms + t * 5;
+        mk[0] = (uint8_t)k0;
+        mk[1] = (uint8_t)k1;
+        mk[2] = (uint8_t)k2;
+        mk[3] = (uint8_t)k3;
+        mk[4] = (uint8_t)k4;
+      }
     }
   }
   wave_lds_fence();

@@ -260,20 +260,24 @@ def test_vector_env_needs_a_gpu_and_has_no_host_path():
 
 
 @pytest.mark.gpu
-def test_vector_env_matches_scalar_restatement_on_hip_states():
+@pytest.mark.parametrize("W,Hh,P", [(10, 10, 2), (15, 15, 2), (7, 5, 2), (25, 25, 4), (21, 13, 3)],
+                         ids=["10x10", "15x15_odd_planes", "7x5_odd_planes", "25x25_odd_planes", "21x13_odd_planes"])
+def test_vector_env_matches_scalar_restatement_on_hip_states(W, Hh, P):
+    """Observation and mask of the gym kernels against the scalar restatement of generals_env.py - also on boards whose
+    planes (W*H floats) start on no 16-byte boundary: those leave through the aligned-window stores of gym_emit."""
     from generalsreinforcementlearning_amd.vector_env import GeneralsVecEnv
-    env = GeneralsVecEnv(32, board_width=10, board_height=10, max_players=2, max_turns=100, seed=9)
+    env = GeneralsVecEnv(32, board_width=W, board_height=Hh, max_players=P, max_turns=100, seed=9)
     obs, info = env.reset()
     rng = np.random.default_rng(1)
-    for k in range(40):
+    for k in range(40 if W * Hh < 300 else 12):
         acts = np.array([rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in info["valid_actions_mask"]])
         obs, reward, terminated, truncated, info = env.step(acts)
         st = env.engine.game_state()
         vis, fog = env.engine.compute_player_visibility(0)
         for e in range(0, 32, 5):
             tiles = ref_proto_tiles(st["owner"][e], st["army"][e], st["type"][e], vis[e], fog[e])
-            assert np.array_equal(obs[e], ref_get_observation(tiles, 10, 10, 0, int(info["turn"][e]), 100))
-            assert np.array_equal(info["valid_actions_mask"][e], ref_valid_mask(tiles, 10, 10, 0))
+            assert np.array_equal(obs[e], ref_get_observation(tiles, W, Hh, 0, int(info["turn"][e]), 100)), (k, e)
+            assert np.array_equal(info["valid_actions_mask"][e], ref_valid_mask(tiles, W, Hh, 0)), (k, e)
     env.close()
 
 
