@@ -602,12 +602,19 @@ struct ExpandArgs {
 };
 
 // own / vis / types / army: this wave's LDS copy of the record; any: OR of the P ownership planes
+// One StateToTensor of an expanded record.  Its nine planes are N = W*H floats each, back to back: for most boards no plane
+// starts on a 256-byte boundary (15x15: 900 bytes; 20x20: 1,600), and stores of "tiles 64j .. 64j+63" that begin anywhere
+// in a line leave at a third of the rate of aligned ones (32,768 records: 15x15 and 25x25 expanded at 1.9 TB/s, 16x16 and
+// 32x32 at 5.9-6.3).  So every store covers an ALIGNED window of 64 floats: lane l of window k holds tile 64k - sh + l of its
+// plane (sh: the plane's dword offset inside its 256-byte line); the bits come from the record in LDS, where any tile is
+// as near as any other.
 __device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own_p, const uint32_t* any, const uint32_t* vis_p, const uint32_t* types,
                                               const uint16_t* army, int fd, int N, int stride, bool fog) {
   const int lane = lane_id();
-  for (int t0 = 0; t0 < N; t0 += 64) {
-    const int t = t0 + lane;
-    if (t < N) {
+  const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 2);
+  if (((a0 | (uint32_t)N) & 63u) == 0u) {
+    // planes that are aligned by themselves (16x16, 32x32): one pass over the tiles, the record's bits read once for all nine
+    for (int t = lane; t < N; t += 64) {
       const int dwi = t >> 5;
       const uint32_t bit = 1u << (t & 31);
       const bool owned = (any[dwi] & bit) != 0u, mine = (own_p[dwi] & bit) != 0u, seen = (vis_p[dwi] & bit) != 0u;
@@ -628,6 +635,41 @@ __device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own_p,
       st_stream<GVEC_NT_MASK>(out + 6 * n + t, (visible && mount) ? 1.0f : 0.0f);
       st_stream<GVEC_NT_MASK>(out + 7 * n + t, visible ? 1.0f : 0.0f);
       st_stream<GVEC_NT_MASK>(out + 8 * n + t, visible ? 0.0f : 1.0f);
+    }
+  } else
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    float* plane = out + (size_t)c * (size_t)N;
+    const int sh = (int)((a0 + (uint32_t)c * (uint32_t)N) & 63u);
+    for (int t = lane - sh; t < N; t += 64) {
+      if (t < 0) continue;
+      const int dwi = t >> 5;
+      const uint32_t bit = 1u << (t & 31);
+      const bool seen = (vis_p[dwi] & bit) != 0u, mount = (types[2 * fd + dwi] & bit) != 0u;
+      const bool visible = !fog || seen;      // :50
+      const bool open = visible && !mount;    // mountains short-circuit (:68-71)
+      float v;
+      if (c <= 3) {
+        const bool owned = (any[dwi] & bit) != 0u, mine = (own_p[dwi] & bit) != 0u;
+        const bool who = (c & 1) ? (!mine && owned) : mine;      // 0, 2: the player's own; 1, 3: somebody else's
+        if (c < 2) {
+          const int a = (int)army[t];
+          float norm = (float)a / 1000.0f;    // :82-85
+          norm = norm > 1.0f ? 1.0f : norm;
+          v = (open && who && a > 0) ? norm : 0.0f;
+        } else {
+          v = (open && who) ? 1.0f : 0.0f;
+        }
+      } else if (c == 4) {
+        v = (open && !(any[dwi] & bit)) ? 1.0f : 0.0f;
+      } else if (c == 5) {
+        v = (open && ((types[dwi] | types[fd + dwi]) & bit)) ? 1.0f : 0.0f;
+      } else if (c == 6) {
+        v = (visible && mount) ? 1.0f : 0.0f;
+      } else {
+        v = (visible == (c == 7)) ? 1.0f : 0.0f;
+      }
+      st_stream<GVEC_NT_MASK>(plane + t, v);
     }
   }
   for (int i = 9 * N + lane; i < 9 * stride; i += 64) out[i] = 0.0f;  // a smaller board in a padded batch: clear the rest of the slot
@@ -701,7 +743,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void expand_records_kernel(Ex
     expand_tensor(nx, next_own + p * fd, any_next, next_vis + p * fd, types, army_next, fd, N, A.stride, (flags & 2u) != 0u);
     // GenerateActionMask as bytes, four per tile (t*4 + d): one dword store per tile
     const uint32_t* m = rec + off_mask + p * 4 * fd;   // [d][fd]
-    for (int t = lane; t < A.stride; t += 64) {
+    const int msh = (int)((reinterpret_cast<uintptr_t>(mk) >> 2) & 63u);       // aligned windows here too
+    for (int t = lane - msh; t < A.stride; t += 64) {
+      if (t < 0) continue;
       uint32_t v = 0u;
       if (t < N) {
         const int dwi = t >> 5, sh = t & 31;
