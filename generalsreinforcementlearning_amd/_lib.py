@@ -104,7 +104,8 @@ SYMBOLS = {
 
 
 def lib_path():
-    return os.path.join(_PKG, "libgvec_hip.so")
+    """The in-tree build; GVEC_LIB names another build of the same library (A/B measurements of two builds)."""
+    return os.environ.get("GVEC_LIB") or os.path.join(_PKG, "libgvec_hip.so")
 
 
 def load_from(path):
