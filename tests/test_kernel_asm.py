@@ -50,3 +50,21 @@ def test_wide_asm_stores_keep_their_wait_states(unit):
                 a = int(dst.group(1) or dst.group(3))
                 b = int(dst.group(2) or dst.group(3))
                 assert b < lo or a > hi, f"{unit}: `{ins[i]}` is followed within 2 wait states by `{ins[i + k]}`"
+
+
+def test_no_cross_lane_read_behind_a_short_circuit():
+    """ds_bpermute / DPP read zeros from lanes that are masked off in EXEC.  A `cond && gather(...)` whose `cond` differs
+    between lanes evaluates the gather for some lanes only - and the others' bits vanish from what the active lanes read (the
+    first aligned-window version of gym_emit lost its type planes that way).  The kernels' idiom is: cross-lane reads into
+    locals first, then the logic; this scan keeps it that way."""
+    import re
+    src_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "generalsreinforcementlearning_amd", "csrc")
+    pat = re.compile(r"(&&|\|\||\?)\s*!?\s*(at|arm_at|bperm|rdlane_any|b\.gather|b\.gather_mask|gather|gather_mask)\s*\(")
+    bad = []
+    for name in sorted(os.listdir(src_dir)):
+        if name.endswith((".hip", ".hpp")):
+            for i, line in enumerate(open(os.path.join(src_dir, name)), 1):
+                code = line.split("//")[0]
+                if pat.search(code):
+                    bad.append(f"{name}:{i}: {line.strip()}")
+    assert not bad, "\n".join(bad)
