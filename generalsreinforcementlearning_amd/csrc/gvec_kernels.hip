@@ -933,6 +933,76 @@ __device__ __forceinline__ void gym_emit(const BT& b, uint32_t seen, uint32_t ow
         mk[4] = (uint8_t)k4;
       }
     }
+  } else if constexpr (NSLOT >= 7) {
+    // Boards of more than 256 tiles whose planes are a multiple of four floats on 16-byte boundaries (20x20, 24x25, 32x32):
+    // FOUR neighbouring tiles per lane.  (65,536 envs: 20x20 0.255 -> 0.241 ms; smaller boards leave too many lanes without
+    // a quad - 10x10 0.144 -> 0.159, 16x16 0.184 -> 0.195 - and keep the per-slot form below.)  Their bits are one nibble
+    // of a plane's dword - one ds_bpermute per plane and 256 tiles instead of one per 64 - their armies one 16-byte LDS read,
+    // each of the nine stores a 1-KB run of the wave, and the twenty mask bytes of the four tiles five dwords into the stage.
+    const int nq = stride >> 2;
+    constexpr int QI = (NSLOT + 3) / 4;
+    int32_t* as = reinterpret_cast<int32_t*>(ms);             // the stage first carries the armies, tile t at dword t
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) as[64 * s + lane] = b.army[s];
+    wave_lds_fence();
+    int4 a4[QI];
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      const int q = lane + 64 * i;
+      a4[i] = (q < nq) ? *reinterpret_cast<const int4*>(as + 4 * q) : make_int4(0, 0, 0, 0);
+    }
+    wave_lds_fence();                                         // ... and is free for the mask bytes from here on
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      if (64 * i < nq) {                                      // wave-uniform: the bpermutes below need every lane
+        const int q = lane + 64 * i;
+        const bool ok = q < nq;
+        const int qq = ok ? q : 0;
+        const int from = (qq >> 3) << 2, sh4 = (qq & 7) << 2;
+        const uint32_t n_vis = (bperm(from, seen) >> sh4) & 15u, n_mine = (bperm(from, own_p) >> sh4) & 15u;
+        const uint32_t n_any = (bperm(from, own_any) >> sh4) & 15u, n_g = (bperm(from, b.gen) >> sh4) & 15u;
+        const uint32_t n_c = (bperm(from, b.city) >> sh4) & 15u, n_mt = (bperm(from, b.mtn) >> sh4) & 15u;
+        uint32_t kd[5];
+        kd[0] = (bperm(from, m0) >> sh4) & 15u;
+        kd[1] = (bperm(from, m1) >> sh4) & 15u;
+        kd[2] = (bperm(from, m2) >> sh4) & 15u;
+        kd[3] = (bperm(from, m3) >> sh4) & 15u;
+        kd[4] = (bperm(from, many) >> sh4) & 15u;
+        const int t0 = qq << 2, left = b.N - t0;              // a smaller board in a padded batch ends inside or before the quad
+        const uint32_t n_in = left >= 4 ? 15u : (left <= 0 ? 0u : ((1u << left) - 1u));
+        const uint32_t v = n_vis & n_in;
+        if (ok) {
+          const size_t n = (size_t)stride;
+          auto put = [&](int p, float x, float y, float z, float w) {
+            float4 o;
+            o.x = x; o.y = y; o.z = z; o.w = w;
+            st_stream<GVEC_NT_MASK>(reinterpret_cast<u32x4*>(obs + p * n) + q, *reinterpret_cast<const u32x4*>(&o));
+          };
+          auto ones = [&](int p, uint32_t m) { put(p, (m & 1u) ? 1.0f : 0.0f, (m & 2u) ? 1.0f : 0.0f, (m & 4u) ? 1.0f : 0.0f, (m & 8u) ? 1.0f : 0.0f); };
+          ones(0, v);                                                                                         // :312-314
+          const uint32_t mine = v & n_mine, other = v & ~n_mine & n_any;                                      // :316-322 (owner -1 unless visible)
+          put(1, (mine & 1u) ? 0.5f : ((other & 1u) ? 1.0f : 0.0f), (mine & 2u) ? 0.5f : ((other & 2u) ? 1.0f : 0.0f),
+              (mine & 4u) ? 0.5f : ((other & 4u) ? 1.0f : 0.0f), (mine & 8u) ? 0.5f : ((other & 8u) ? 1.0f : 0.0f));
+          // channel 2: np.log(army + 1) / 10.0 in float64, cast on store (:324-326); hidden and fogged tiles: army 0
+          auto la = [](bool shown, int32_t a) { return (shown && a > 0) ? (float)(log((double)a + 1.0) / 10.0) : 0.0f; };
+          put(2, la((v & 1u) != 0u, a4[i].x), la((v & 2u) != 0u, a4[i].y), la((v & 4u) != 0u, a4[i].z), la((v & 8u) != 0u, a4[i].w));
+          ones(3, n_in & ~n_g & ~n_c & ~n_mt);                                                                // :328-336 one-hot type
+          ones(4, n_in & n_mt);
+          ones(5, n_in & n_c);
+          ones(6, n_in & n_g);
+          put(7, tc, tc, tc, tc);                                                                             // the whole plane, like obs[7, :, :] = ...
+          put(8, 0.0f, 0.0f, 0.0f, 0.0f);                                                                     // left zero by the reference (:341-343)
+          // mask byte 5 * tile + d of the quad's four tiles: twenty bytes = five dwords at byte 20 * q of the stage
+          uint32_t w[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int bb = 0; bb < 20; ++bb) w[bb >> 2] |= ((kd[bb % 5] >> (bb / 5)) & 1u) << (8 * (bb & 3));
+          uint32_t* mw = reinterpret_cast<uint32_t*>(ms) + 5 * q;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) mw[k] = w[k];
+        }
+      }
+    }
+  
   } else {
   #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
@@ -963,6 +1033,7 @@ __device__ __forceinline__ void gym_emit(const BT& b, uint32_t seen, uint32_t ow
         mk[4] = (uint8_t)k4;
       }
     }
+  
   }
   wave_lds_fence();
   // the mask is five bytes per tile: laid out in LDS above and stored as whole 16-byte (or 4-byte) pieces of consecutive
