@@ -612,29 +612,43 @@ __device__ __forceinline__ void expand_tensor(float* out, const uint32_t* own_p,
                                               const uint16_t* army, int fd, int N, int stride, bool fog) {
   const int lane = lane_id();
   const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 2);
-  if (((a0 | (uint32_t)N) & 63u) == 0u) {
-    // planes that are aligned by themselves (16x16, 32x32): one pass over the tiles, the record's bits read once for all nine
-    for (int t = lane; t < N; t += 64) {
-      const int dwi = t >> 5;
-      const uint32_t bit = 1u << (t & 31);
-      const bool owned = (any[dwi] & bit) != 0u, mine = (own_p[dwi] & bit) != 0u, seen = (vis_p[dwi] & bit) != 0u;
-      const bool spec = ((types[dwi] | types[fd + dwi]) & bit) != 0u, mount = (types[2 * fd + dwi] & bit) != 0u;
-      const bool visible = !fog || seen;      // :50
-      const bool open = visible && !mount;    // mountains short-circuit (:68-71)
-      const int a = (int)army[t];
-      float norm = (float)a / 1000.0f;        // :82-85
-      norm = norm > 1.0f ? 1.0f : norm;
-      const float arm = (a > 0) ? norm : 0.0f;
+  if (((a0 | (uint32_t)N) & 3u) == 0u) {
+    // planes of a multiple of four floats on 16-byte boundaries (10x10, 16x16, 20x20, 32x32 ...): FOUR neighbouring tiles per
+    // lane - a nibble of each of the record's planes, four u16 armies in one LDS read, nine 1-KB stores per 256 tiles, which
+    // (unlike 256-byte runs of dwords) leave at full rate wherever they start
+    auto nib = [&](const uint32_t* plane, int q) { return (plane[q >> 3] >> ((q & 7) << 2)) & 15u; };
+    for (int q = lane; q < (N >> 2); q += 64) {
+      const uint32_t n_any = nib(any, q), n_mine = nib(own_p, q), n_seen = nib(vis_p, q);
+      const uint32_t n_spec = nib(types, q) | nib(types + fd, q), n_mtn = nib(types + 2 * fd, q);
+      const uint32_t n_vis = fog ? n_seen : 15u;                   // :50
+      const uint32_t n_open = n_vis & ~n_mtn;                      // mountains short-circuit (:68-71)
+      const uint32_t* ap = reinterpret_cast<const uint32_t*>(army) + 2 * q;    // the record's armies are dword-aligned in LDS
+      const uint2 aw = make_uint2(ap[0], ap[1]);
+      auto arm = [](uint32_t a) {
+        float norm = (float)(int)a / 1000.0f;                      // :82-85
+        norm = norm > 1.0f ? 1.0f : norm;
+        return (a > 0u) ? norm : 0.0f;
+      };
+      const float r0 = arm(aw.x & 0xFFFFu), r1 = arm(aw.x >> 16), r2 = arm(aw.y & 0xFFFFu), r3 = arm(aw.y >> 16);
       const size_t n = (size_t)N;
-      st_stream<GVEC_NT_MASK>(out + 0 * n + t, (open && mine) ? arm : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 1 * n + t, (open && !mine && owned) ? arm : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 2 * n + t, (open && mine) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 3 * n + t, (open && !mine && owned) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 4 * n + t, (open && !owned) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 5 * n + t, (open && spec) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 6 * n + t, (visible && mount) ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 7 * n + t, visible ? 1.0f : 0.0f);
-      st_stream<GVEC_NT_MASK>(out + 8 * n + t, visible ? 0.0f : 1.0f);
+      auto put = [&](int c, uint32_t m, float v0, float v1, float v2, float v3) {
+        float4 o;
+        o.x = (m & 1u) ? v0 : 0.0f;
+        o.y = (m & 2u) ? v1 : 0.0f;
+        o.z = (m & 4u) ? v2 : 0.0f;
+        o.w = (m & 8u) ? v3 : 0.0f;
+        st_stream<GVEC_NT_MASK>(reinterpret_cast<u32x4*>(out + c * n) + q, *reinterpret_cast<const u32x4*>(&o));
+      };
+      const uint32_t m_mine = n_open & n_mine, m_other = n_open & ~n_mine & n_any;
+      put(0, m_mine, r0, r1, r2, r3);
+      put(1, m_other, r0, r1, r2, r3);
+      put(2, m_mine, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(3, m_other, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(4, n_open & ~n_any, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(5, n_open & n_spec, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(6, n_vis & n_mtn, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(7, n_vis, 1.0f, 1.0f, 1.0f, 1.0f);
+      put(8, ~n_vis & 15u, 1.0f, 1.0f, 1.0f, 1.0f);
     }
   } else
 #pragma unroll
