@@ -102,3 +102,14 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     assert L.gvec_create_sharded(C.byref(cfg), (C.c_int32 * 1)(0), 0, C.byref(h)) == -1
     out = C.c_void_p()
     assert L.gvec_host_alloc(0, C.byref(out)) == -1 and L.gvec_host_free(None) == 0
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table says which reference interface each exported function replaces: none may be missing from it."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "generals_vec.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [s for s in sorted(set(re.findall(r"\b(gvec_[a-z_0-9]+)\s*\(", hdr))) if s not in doc]
+    assert not missing, missing
