@@ -236,19 +236,8 @@ class RecordReplayRing:
         return self.size
 
     def sample_indices(self, k):
-        if k > self.size or k < 0:
-            raise ValueError("Sample larger than population or is negative")
-        t = self._t
-        if self.size <= (1 << 16) or 4 * k >= self.size:
-            return t.randperm(self.size, device=self.device, generator=self._gen)[:k]
-        got = t.empty(0, dtype=t.int64, device=self.device)
-        while got.numel() < k:                                   # big ring, small draw: draw, drop repeats, top up
-            both = t.cat([got, t.randint(self.size, (2 * (k - got.numel()) + 16,), device=self.device, generator=self._gen)])
-            uniq, inverse = t.unique(both, return_inverse=True)
-            first = t.full((uniq.numel(),), both.numel(), dtype=t.int64, device=self.device).scatter_reduce_(
-                0, inverse, t.arange(both.numel(), device=self.device), reduce="amin")
-            got = both[first.sort().values]
-        return got[:k]
+        from ._sampling import distinct_indices
+        return distinct_indices(self._t, self.size, k, self.device, self._gen)
 
     def sample(self, k, indices=None):
         """-> decode_records' batch dict as CUDA tensors (state / next_state [m, 9 * stride] with an experience's own

@@ -440,3 +440,26 @@ def test_reference_shaped_training_code_runs_on_the_drop_in_names():
     with pytest.raises(RuntimeError) as err:                 # like a factory that fails: retried, then the pool gives up
         wrong.collect(1)
     assert isinstance(err.value.__cause__, TypeError)
+
+
+@pytest.mark.gpu
+def test_device_replay_buffer_draws_distinct_slots_from_a_big_ring():
+    """Past 65,536 transitions a small draw no longer permutes the whole ring: it draws with replacement, drops repeats and
+    tops up - still batch_size DISTINCT slots, all inside the filled part, different from draw to draw."""
+    import torch
+    from generalsreinforcementlearning_amd.env_pool import DeviceReplayBuffer
+    buf = DeviceReplayBuffer(200_000)
+    n = 150_000
+    s = torch.arange(n, dtype=torch.float32, device="cuda").reshape(n, 1, 1, 1).expand(n, 2, 2, 2).contiguous()
+    buf.push_batch(s, torch.arange(n), torch.zeros(n), s + 0.5, torch.zeros(n, dtype=torch.bool))
+    assert len(buf) == n and buf.total_pushed == n
+    buf.manual_seed(5)
+    a = buf.sample_indices(4096)
+    b = buf.sample_indices(4096)
+    for idx in (a, b):
+        assert idx.numel() == 4096 and idx.unique().numel() == 4096 and int(idx.min()) >= 0 and int(idx.max()) < n
+    assert not torch.equal(a, b) and int(a.max()) > n // 2              # spread over the ring, not a prefix
+    st, ac, rw, ns, dn = buf.sample_arrays(512)
+    assert torch.equal(st[:, 0, 0, 0].long(), ac) and torch.equal(ns, st + 0.5)      # a row's fields belong together
+    with pytest.raises(ValueError):
+        buf.sample_indices(n + 1)
