@@ -282,9 +282,12 @@ class DeviceReplayBuffer:
         return got[:batch_size]
 
     def sample_arrays(self, batch_size):
-        """(states, actions, rewards, next_states, dones) as CUDA tensors."""
-        idx = self.sample_indices(batch_size)
-        return self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx], self.done[idx]
+        """(states, actions, rewards, next_states, dones) as CUDA tensors.  The draw and its five gathers are enqueued under
+        the lock a collector's launches take too, so no vector step lands between them: a drawn slot's fields belong to ONE
+        transition even while the ring is being overwritten (the reference samples under its lock as well, :40-43)."""
+        with self._guard:
+            idx = self.sample_indices(batch_size)
+            return self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx], self.done[idx]
 
     def sample(self, batch_size):
         """The reference's return type - a list of (state, action, reward, next_state, done) tuples - on the host."""
@@ -349,7 +352,8 @@ class _DeviceCollector:
         a.state, a.next_state, a.action, a.reward = state.data_ptr(), next_state.data_ptr(), actions.data_ptr(), reward.data_ptr()
         a.terminated, a.truncated, a.was_reset, a.needs_reset = terminated.data_ptr(), truncated.data_ptr(), was_reset.data_ptr(), needs_reset.data_ptr()
         stream = self._t.cuda.current_stream(self.env._dev).cuda_stream
-        self._check(self.L.gvec_pool_collect(self._device_index, stream, self._C.byref(a)), "gvec_pool_collect")
+        with self.buffer._guard:                  # ordered against a learner's sample_arrays / push_batch on the same stream
+            self._check(self.L.gvec_pool_collect(self._device_index, stream, self._C.byref(a)), "gvec_pool_collect")
 
     def pop_results(self):
         held = int(self.counters[1])
