@@ -186,102 +186,6 @@ class DeviceReplayBuffer:
         return distinct_indices(self._t, len(self), batch_size, self.device, self._gen)
 
     def sample_arrays(self, batch_size):
-        """The same draw as stacked arrays: (states, actions, rewards, next_states, dones)."""
-        with self._guard:
-            idx = np.asarray(random.sample(range(self._size), batch_size), np.int64)
-            return self._state[idx], self._action[idx], self._reward[idx], self._next[idx], self._done[idx]
-
-    @property
-    def total_pushed(self):
-        with self._guard:
-            return self._pushed
-
-    def __len__(self):
-        with self._guard:
-            return self._size
-
-
-class DeviceReplayBuffer:
-    """The replay ring resident in HBM: what `ReplayBuffer` is to a host collector, for a pool that never leaves the GPU
-    (`ParallelVecEnvPool` over a `GeneralsVecEnv(device_outputs=True)`).  Transitions are appended by `gvec_pool_collect`
-    (one wavefront moves one row) straight from the gym kernel's output buffers; `sample_arrays` gathers a batch into CUDA
-    tensors a learner consumes in place.  288 GB of HBM hold 17 million 15x15 transitions (2 x 8,100 B of observation each).
-    Same semantics as replay_buffer.py:13-55 - the oldest transition is overwritten once `capacity` is reached, `sample`
-    draws uniformly without replacement and raises ValueError when fewer than batch_size are held, `total_pushed` counts
-    every push - with one difference: the draw comes from a torch generator on the device, not from `random`."""
-
-    def __init__(self, capacity, device=0):
-        if capacity <= 0:
-            raise ValueError(f"capacity must be positive, got {capacity}")
-        import torch
-        self._t = torch
-        self.capacity = int(capacity)
-        self.device = torch.device("cuda", device)
-        self.counters = torch.zeros(4, dtype=torch.int64, device=self.device)     # cursor, size, total pushed, 0
-        self.state = self.next_state = self.action = self.reward = self.done = None
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(0)
-        self._guard = threading.Lock()
-
-    def allocate(self, obs_shape):
-        """The five slabs of the ring (at the first push; a collector calls it with the env's observation shape)."""
-        if self.state is None:
-            t, dev, cap = self._t, self.device, self.capacity
-            self.obs_shape = tuple(obs_shape)
-            self.state = t.empty((cap,) + self.obs_shape, dtype=t.float32, device=dev)
-            self.next_state = t.empty((cap,) + self.obs_shape, dtype=t.float32, device=dev)
-            self.action = t.empty(cap, dtype=t.int64, device=dev)
-            self.reward = t.empty(cap, dtype=t.float64, device=dev)
-            self.done = t.empty(cap, dtype=t.bool, device=dev)
-        return self
-
-    def manual_seed(self, seed):
-        self._gen.manual_seed(int(seed))
-
-    def push_batch(self, states, actions, rewards, next_states, dones):
-        """k transitions in order, for a learner that pushes by itself (the pool appends through gvec_pool_collect)."""
-        t = self._t
-        dev = self.device
-        actions = t.as_tensor(actions, dtype=t.int64, device=dev).reshape(-1)
-        k = int(actions.numel())
-        if k == 0:
-            return
-        states = t.as_tensor(states, dtype=t.float32, device=dev)
-        next_states = t.as_tensor(next_states, dtype=t.float32, device=dev)
-        with self._guard:
-            self.allocate(states.shape[1:])
-            cursor, size, pushed = (int(v) for v in self.counters[:3].tolist())
-            lo = max(0, k - self.capacity)                                    # only the last `capacity` survive, as with k pushes
-            idx = (cursor + t.arange(lo, k, device=dev)) % self.capacity
-            self.state[idx], self.next_state[idx] = states[lo:], next_states[lo:]
-            self.action[idx] = actions[lo:]
-            self.reward[idx] = t.as_tensor(rewards, dtype=t.float64, device=dev).reshape(-1)[lo:]
-            self.done[idx] = t.as_tensor(dones, dtype=t.bool, device=dev).reshape(-1)[lo:]
-            self.counters[:3] = t.tensor([(cursor + k) % self.capacity, min(size + k, self.capacity), pushed + k], dtype=t.int64)
-
-    def push(self, state, action, reward, next_state, done):
-        t = self._t
-        self.push_batch(t.as_tensor(state)[None], [action], [reward], t.as_tensor(next_state)[None], [done])
-
-    def sample_indices(self, batch_size):
-        """batch_size distinct slots, uniformly over the transitions held (random.sample's contract, replay_buffer.py:40-43)."""
-        t = self._t
-        size = len(self)
-        if batch_size > size or batch_size < 0:
-            raise ValueError("Sample larger than population or is negative")          # random.sample's own words
-        if size <= (1 << 16) or 4 * batch_size >= size:
-            return t.randperm(size, device=self.device, generator=self._gen)[:batch_size]
-        got = t.empty(0, dtype=t.int64, device=self.device)                            # big ring, small batch: draw, drop repeats, top up
-        while got.numel() < batch_size:
-            draw = t.randint(size, (2 * (batch_size - got.numel()) + 16,), device=self.device, generator=self._gen)
-            both = t.cat([got, draw])
-            uniq, inverse = t.unique(both, return_inverse=True)
-            first = t.full((uniq.numel(),), both.numel(), dtype=t.int64, device=self.device).scatter_reduce_(
-                0, inverse, t.arange(both.numel(), device=self.device), reduce="amin")
-            got = both[first.sort().values]                                            # first occurrences, in drawing order
-        return got[:batch_size]
-
-    def sample_arrays(self, batch_size):
         """(states, actions, rewards, next_states, dones) as CUDA tensors.  The draw and its five gathers are enqueued under
         the lock a collector's launches take too, so no vector step lands between them: a drawn slot's fields belong to ONE
         transition even while the ring is being overwritten (the reference samples under its lock as well, :40-43)."""
